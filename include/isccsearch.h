@@ -1,0 +1,140 @@
+/*
+ * isccsearch.h -- C-ABI of libisccsearch_hip.so, the MI355X (gfx950) brute-force
+ * Hamming / NPHD k-nearest-neighbour engine behind the `hip:///` ISCC index backend.
+ *
+ * Drop-in boundary.  The reference (iscc/iscc-search, 100 % Python) reaches its hot path through
+ * two third-party objects; every entry point below replaces one of their methods at the call
+ * sites listed (paths relative to the reference tree):
+ *
+ *   iscc_usearch.ShardedNphdIndex   (metric = ISCCSEARCH_METRIC_NPHD, 64-bit keys)
+ *     ctor    iscc_search/indexes/usearch/index.py:1617-1625   -> isccsearch_table_open
+ *     .add    iscc_search/indexes/usearch/index.py:440         -> isccsearch_add
+ *     .remove iscc_search/indexes/usearch/index.py:436         -> isccsearch_remove
+ *     .search iscc_search/indexes/usearch/index.py:2037        -> isccsearch_search
+ *     `in`    iscc_search/indexes/usearch/index.py:560         -> isccsearch_contains
+ *     .size   iscc_search/indexes/usearch/index.py:444,1631    -> isccsearch_size
+ *     .reset/.close  index.py:1699, :936                       -> isccsearch_table_drop / isccsearch_destroy
+ *   iscc_usearch.ShardedIndex128    (metric = ISCCSEARCH_METRIC_HAMMING, 128-bit keys)
+ *     ctor    iscc_search/indexes/simprint/usearch_core.py:73-83 -> isccsearch_table_open
+ *     .add    iscc_search/indexes/simprint/usearch_core.py:108   -> isccsearch_add
+ *     .remove iscc_search/indexes/simprint/usearch_core.py:119   -> isccsearch_remove
+ *     .search iscc_search/indexes/simprint/usearch_core.py:165   -> isccsearch_search
+ *     .get    iscc_search/indexes/simprint/usearch_core.py:221   -> isccsearch_get
+ *     `in`    iscc_search/indexes/simprint/usearch_core.py:135   -> isccsearch_contains
+ *
+ * Unlike the reference's HNSW, every search here is EXACT: the k rows with the smallest
+ * (distance, key), ascending, where distance is the rational hamming/prefix_bits for NPHD tables
+ * and the raw bit count for Hamming tables (the reference leaves tie order unspecified,
+ * iscc_search/indexes/usearch/index.py:836; this library defines it).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller allocates every output; the library owns device memory
+ *   - return 0 on success, a negative errno-style code otherwise; isccsearch_last_error() returns
+ *     a thread-local human-readable message for the last failure on the calling thread
+ *   - every entry point takes the handle's mutex: calls from many threads are serialised
+ *   - codes are handed over as 64-bit words: the code's bytes packed BIG-ENDIAN (byte 0 is the
+ *     most significant byte of word 0), zero padded to max_words = ceil(max_bytes / 8) words
+ *   - 128-bit keys are two words (hi, lo) of the big-endian 16-byte key
+ *     (iscc_search/indexes/simprint/lmdb_ops.py:30-49: iscc_id_body(8) | offset(4) | size(4))
+ */
+#ifndef ISCCSEARCH_H
+#define ISCCSEARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISCCSEARCH_METRIC_HAMMING 0 /* fixed length, distance = differing bits                    */
+#define ISCCSEARCH_METRIC_NPHD    1 /* variable length, distance = hamming(prefix) / prefix bits  */
+
+#define ISCCSEARCH_MAX_BYTES 32     /* longest code: 256 bits (index.py:135 max_dim)              */
+#define ISCCSEARCH_MAX_K     4096   /* largest k per search (reference default limit 100; simprint
+                                       oversampling 40 x limit = 4000, usearch_core.py:164)        */
+
+#define ISCCSEARCH_ADD_TRUSTED_UNIQUE 1u /* caller guarantees the keys are new (usearch_core.py:89-92
+                                            "skips the expensive contains-check")                   */
+
+typedef struct isccsearch_handle isccsearch_handle;
+
+/* One search result as it lives in device memory (multi-GPU exchange format, 24 bytes). */
+typedef struct isccsearch_record {
+    uint64_t key_hi;      /* 0 for 64-bit keys */
+    uint64_t key_lo;
+    uint32_t dist_rank;   /* order-preserving integer for the exact distance (library internal) */
+    uint16_t hamming;     /* differing bits over the compared prefix */
+    uint16_t prefix_bits; /* bits compared (NPHD denominator; table bit length for Hamming) */
+} isccsearch_record;
+
+typedef struct isccsearch_stats {
+    uint64_t searches;        /* isccsearch_search* calls served                              */
+    uint64_t queries;         /* queries answered                                             */
+    uint64_t scan_launches;   /* launches of the collect scan kernel                          */
+    uint64_t scan_passes;     /* query groups streamed over a segment by those launches       */
+    uint64_t scan_bytes;      /* ALGORITHMIC bytes of those passes: rows * 8 * words compared */
+    double   scan_ms;         /* summed device time of those launches (only while profiling)  */
+    uint64_t sample_bytes;    /* bytes streamed by the threshold (sample) scans               */
+    uint64_t fallback_queries;/* queries that took the exact full-histogram fallback          */
+    uint32_t queries_per_pass;/* T_q: queries held in SGPRs per streaming pass                */
+    uint32_t compute_units;   /* CUs of the device                                            */
+} isccsearch_stats;
+
+/* Engine lifetime.  One handle drives one GPU (one process per GPU). */
+int isccsearch_create(int device_id, isccsearch_handle** out);
+int isccsearch_destroy(isccsearch_handle* h);
+const char* isccsearch_last_error(void);
+
+/* Options: "queries_per_pass" (8|16|32), "profile" (0|1: time every collect-scan launch with HIP
+ * events, read back through isccsearch_stats), "nontemporal" (0|1). */
+int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);
+int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset);
+
+/* Tables.  max_bytes = longest code in bytes (1..32); for Hamming tables every code has exactly
+ * max_bytes bytes.  key_words = 1 (u64 keys) or 2 (128-bit keys). */
+int isccsearch_table_open(isccsearch_handle* h, int metric, int key_words, int max_bytes, uint32_t* table_id);
+int isccsearch_table_drop(isccsearch_handle* h, uint32_t table);
+int isccsearch_reserve(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t rows);
+uint64_t isccsearch_size(isccsearch_handle* h, uint32_t table);
+
+/* Rows.  keys[n*key_words], code_words[n*max_words], nbytes[n] (NULL for Hamming tables).
+ * A key that is already present (or repeated in the batch) fails the whole call with -EEXIST
+ * unless ISCCSEARCH_ADD_TRUSTED_UNIQUE is set. */
+int isccsearch_add(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
+                   const uint64_t* code_words, const uint8_t* nbytes, uint32_t flags);
+int isccsearch_remove(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys, uint64_t* n_removed);
+int isccsearch_contains(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys, uint8_t* out_found);
+/* out_nbytes[i] = 0 when keys[i] is absent; out_words[n*max_words] zero padded */
+int isccsearch_get(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
+                   uint64_t* out_words, uint8_t* out_nbytes);
+
+/* Bench / test helper: append n rows generated ON THE DEVICE, nbytes long each:
+ *   word w of row i = splitmix64(seed + 4*(first_row + i) + w),  key = key_base + first_row + i
+ * (SURVEY.md section 8d synthetic generator).  Rows are not entered into the host key index. */
+int isccsearch_add_synthetic(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t n,
+                             uint64_t seed, uint64_t first_row, uint64_t key_base);
+
+/* Exact k-NN.  q_words[nq*max_words], q_nbytes[nq] (NULL for Hamming tables), 1 <= k <= ISCCSEARCH_MAX_K.
+ * Outputs: out_keys[nq*k*key_words], out_hamming[nq*k], out_prefix_bits[nq*k], out_count[nq]
+ * (= min(k, rows)); entries past out_count are zero. */
+int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                      const uint8_t* q_nbytes, uint32_t k,
+                      uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
+
+/* Multi-GPU building blocks (row-range shards, one process per GPU).
+ * search_device: same search, results left in caller-provided DEVICE memory
+ *   d_records[nq*k] (isccsearch_record), d_counts[nq]; queries must share one byte length.
+ *   The call returns after the library's stream has drained, so the buffers can go straight
+ *   into an RCCL all-gather on any stream.
+ * merge_device: k-way merge of n_lists gathered result sets laid out [n_lists][nq][k] /
+ *   [n_lists][nq] in DEVICE memory into host outputs shaped as for isccsearch_search. */
+int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                             const uint8_t* q_nbytes, uint32_t k, void* d_records, uint32_t* d_counts);
+int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
+                            const void* d_records, const uint32_t* d_counts,
+                            uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISCCSEARCH_H */

@@ -1,0 +1,132 @@
+"""
+ctypes binding of ``libisccsearch_hip.so`` (C-ABI: ``include/isccsearch.h``).
+
+The library is the only compute path of this package: if it cannot be loaded, or no gfx950 device
+can be opened, the functions here raise -- there is no CPU fallback.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libisccsearch_hip.so")
+
+METRIC_HAMMING = 0
+METRIC_NPHD = 1
+MAX_BYTES = 32
+MAX_K = 4096
+ADD_TRUSTED_UNIQUE = 1
+
+# every symbol include/isccsearch.h declares
+EXPORTS = (
+    "isccsearch_create", "isccsearch_destroy", "isccsearch_last_error", "isccsearch_set_option",
+    "isccsearch_stats_get", "isccsearch_table_open", "isccsearch_table_drop", "isccsearch_reserve",
+    "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
+    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_device", "isccsearch_merge_device",
+)
+
+RECORD_DTYPE = np.dtype(
+    [("key_hi", "<u8"), ("key_lo", "<u8"), ("dist_rank", "<u4"), ("hamming", "<u2"), ("prefix_bits", "<u2")]
+)
+assert RECORD_DTYPE.itemsize == 24
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("searches", ctypes.c_uint64),
+        ("queries", ctypes.c_uint64),
+        ("scan_launches", ctypes.c_uint64),
+        ("scan_passes", ctypes.c_uint64),
+        ("scan_bytes", ctypes.c_uint64),
+        ("scan_ms", ctypes.c_double),
+        ("sample_bytes", ctypes.c_uint64),
+        ("fallback_queries", ctypes.c_uint64),
+        ("queries_per_pass", ctypes.c_uint32),
+        ("compute_units", ctypes.c_uint32),
+    ]
+
+    def as_dict(self):
+        # type: () -> dict
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+_LIB = None
+
+
+def load_library():
+    # type: () -> ctypes.CDLL
+    """Load the HIP library and declare its signatures.  Raises RuntimeError when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C iscc_search_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}. There is no CPU fallback.") from e
+    vp, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)
+    u32p, u16p, u8p = ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8)
+    i, u32, u64 = ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
+    sig = {
+        "isccsearch_create": (i, [i, ctypes.POINTER(vp)]),
+        "isccsearch_destroy": (i, [vp]),
+        "isccsearch_last_error": (ctypes.c_char_p, []),
+        "isccsearch_set_option": (i, [vp, ctypes.c_char_p, ctypes.c_int64]),
+        "isccsearch_stats_get": (i, [vp, ctypes.POINTER(Stats), i]),
+        "isccsearch_table_open": (i, [vp, i, i, i, u32p]),
+        "isccsearch_table_drop": (i, [vp, u32]),
+        "isccsearch_reserve": (i, [vp, u32, i, u64]),
+        "isccsearch_size": (u64, [vp, u32]),
+        "isccsearch_add": (i, [vp, u32, u64, u64p, u64p, u8p, u32]),
+        "isccsearch_remove": (i, [vp, u32, u64, u64p, u64p]),
+        "isccsearch_contains": (i, [vp, u32, u64, u64p, u8p]),
+        "isccsearch_get": (i, [vp, u32, u64, u64p, u64p, u8p]),
+        "isccsearch_add_synthetic": (i, [vp, u32, i, u64, u64, u64, u64]),
+        "isccsearch_search": (i, [vp, u32, u32, u64p, u8p, u32, u64p, u32p, u16p, u32p]),
+        "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
+        "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64p, u32p, u16p, u32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def last_error():
+    # type: () -> str
+    msg = load_library().isccsearch_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    # type: (int) -> None
+    """Map the C-ABI's errno-style codes onto the exceptions the reference's callers expect."""
+    if rc == 0:
+        return
+    msg = last_error() or f"isccsearch error {rc}"
+    import errno
+
+    if rc == -errno.EINVAL:
+        raise ValueError(msg)
+    if rc == -errno.EEXIST:
+        raise KeyError(msg)
+    if rc == -errno.ENOENT:
+        raise LookupError(msg)
+    if rc == -errno.ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(arr, ctype):
+    """ctypes pointer to a C-contiguous numpy array (None passes through as NULL)."""
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(ctypes.POINTER(ctype))

@@ -1,0 +1,980 @@
+// isccsearch.hip -- host side of libisccsearch_hip.so (C-ABI declared in include/isccsearch.h).
+//
+// Owns the device-resident column store (tables -> segments by code length -> word columns + key
+// column), the host key index (lazy), and drives the search pipeline of kernels.hip.h:
+//
+//   per (query class, segment):   boot -> [sample scan(HIST) -> pick] -> scan(COLLECT) -> select
+//   per query class:              merge of the per-segment lists (when more than one segment)
+//   per overflowed query (rare):  fullhist -> exact threshold -> scan(COLLECT) into a sized
+//                                 buffer -> select
+//
+// Everything runs on one HIP stream owned by the handle; the only host synchronisation of a
+// search is the final result copy.  Built for gfx950 only (hipcc --offload-arch=gfx950).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/isccsearch.h"
+#include "kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPOK(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? -ENOMEM : -EIO, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                              \
+    } while (0)
+
+struct Key {
+    uint64_t hi, lo;
+    bool operator==(const Key& o) const { return hi == o.hi && lo == o.lo; }
+};
+struct KeyHash {
+    size_t operator()(const Key& k) const {
+        uint64_t x = k.lo * 0x9E3779B97F4A7C15ULL ^ (k.hi + 0xBF58476D1CE4E5B9ULL + (k.lo << 6) + (k.lo >> 2));
+        x ^= x >> 32;
+        return (size_t)x;
+    }
+};
+struct Loc {
+    uint32_t seg;   // segment = code length in bytes
+    uint64_t row;
+};
+
+struct Segment {
+    uint32_t nbytes = 0, W = 0;
+    uint64_t n = 0, cap = 0;
+    uint64_t* col[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t* keys = nullptr;
+    std::vector<uint64_t> hkeys;   // host mirror of the key column, kept only while the table is indexed
+};
+
+struct Table {
+    bool open = false;
+    int metric = 0, key_words = 1, max_bytes = 0, max_words = 0;
+    Segment seg[ISCCSEARCH_MAX_BYTES + 1];
+    bool indexed = false;
+    std::unordered_map<Key, Loc, KeyHash> index;
+    uint64_t total = 0;
+};
+
+constexpr uint32_t QB_MAX = 1024;        // queries per pipeline run
+constexpr uint64_t ROW_ALIGN = 2048;     // column capacities are multiples of the largest tile
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t need) {
+        if (need <= n) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return fail(-ENOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+        n = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+uint64_t mask_for(uint32_t pbytes) {   // mask of the last compared word for a prefix of pbytes bytes
+    const uint32_t rem = pbytes & 7;
+    return rem ? ~0ULL << (8 * (8 - rem)) : ~0ULL;
+}
+uint32_t next_pow2(uint32_t v) { uint32_t p = 2; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+struct isccsearch_handle {
+    std::mutex mu;
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    std::vector<std::unique_ptr<Table>> tables;
+    // options
+    int tq = 16;
+    bool profile = false;
+    bool nontemporal = true;
+    // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
+    uint16_t* d_rank = nullptr;
+    // scratch
+    DevBuf<uint64_t> d_queries;     // [nq_pad][4]
+    DevBuf<uint32_t> d_bias, d_cnt, d_ghist, d_overflow, d_listcnt, d_outcnt;
+    DevBuf<uint64_t> d_cand;
+    DevBuf<isk::Record> d_lists, d_final;
+    DevBuf<uint64_t> d_misc;        // moves / gather rows / single query
+    DevBuf<uint64_t> d_misc2;
+    std::vector<isk::Record> h_final;
+    std::vector<uint32_t> h_cnt, h_overflow;
+    // profiling
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    isccsearch_stats stats{};
+};
+
+namespace {
+
+using H = isccsearch_handle;
+
+void build_rank_table(std::vector<uint16_t>& rank) {
+    // rank[p][h] for p in 1..32 bytes: position of h/(8p) among all distinct fractions; row 0: identity
+    struct Fr { uint32_t h, p; };
+    std::vector<Fr> all;
+    for (uint32_t p = 1; p <= 32; ++p)
+        for (uint32_t h = 0; h <= 8 * p; ++h) all.push_back({h, p});
+    auto less = [](const Fr& a, const Fr& b) { return (uint64_t)a.h * b.p < (uint64_t)b.h * a.p; };
+    std::sort(all.begin(), all.end(), less);
+    rank.assign(33 * 257, 0xFFFF);
+    uint32_t r = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (i && less(all[i - 1], all[i])) ++r;
+        rank[all[i].p * 257 + all[i].h] = (uint16_t)r;
+    }
+    for (uint32_t h = 0; h <= 256; ++h) rank[h] = (uint16_t)h;
+}
+
+int seg_reserve(H* h, Table& t, Segment& s, uint64_t need) {
+    if (need <= s.cap) return 0;
+    uint64_t cap = std::max<uint64_t>(need, s.cap * 2);
+    cap = (cap + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+    uint64_t* ncol[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t* nkeys = nullptr;
+    auto cleanup = [&]() { for (auto& c : ncol) if (c) (void)hipFree(c); if (nkeys) (void)hipFree(nkeys); };
+    for (uint32_t w = 0; w < s.W; ++w) {
+        hipError_t e = hipMalloc((void**)&ncol[w], cap * 8);
+        if (e != hipSuccess) { cleanup(); return fail(-ENOMEM, "hipMalloc(column, %llu bytes) failed: %s", (unsigned long long)cap * 8, hipGetErrorString(e)); }
+    }
+    {
+        hipError_t e = hipMalloc((void**)&nkeys, cap * 8 * t.key_words);
+        if (e != hipSuccess) { cleanup(); return fail(-ENOMEM, "hipMalloc(keys) failed: %s", hipGetErrorString(e)); }
+    }
+    if (s.n) {
+        for (uint32_t w = 0; w < s.W; ++w) HIPOK(hipMemcpyAsync(ncol[w], s.col[w], s.n * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPOK(hipMemcpyAsync(nkeys, s.keys, s.n * 8 * t.key_words, hipMemcpyDeviceToDevice, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+    }
+    for (uint32_t w = 0; w < s.W; ++w) { if (s.col[w]) (void)hipFree(s.col[w]); s.col[w] = ncol[w]; }
+    if (s.keys) (void)hipFree(s.keys);
+    s.keys = nkeys;
+    s.cap = cap;
+    return 0;
+}
+
+void seg_free(Segment& s) {
+    for (auto& c : s.col) { if (c) (void)hipFree(c); c = nullptr; }
+    if (s.keys) (void)hipFree(s.keys);
+    s.keys = nullptr;
+    s.n = s.cap = 0;
+    s.hkeys.clear();
+    s.hkeys.shrink_to_fit();
+}
+
+int get_table(H* h, uint32_t id, Table*& out) {
+    if (id >= h->tables.size() || !h->tables[id] || !h->tables[id]->open) return fail(-ENOENT, "table %u is not open", id);
+    out = h->tables[id].get();
+    return 0;
+}
+
+int ensure_index(H* h, Table& t) {
+    if (t.indexed) return 0;
+    t.index.clear();
+    t.index.reserve((size_t)t.total + 16);
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
+        Segment& s = t.seg[b];
+        if (!s.n) { s.hkeys.clear(); continue; }
+        s.hkeys.resize((size_t)s.n * t.key_words);
+        HIPOK(hipMemcpyAsync(s.hkeys.data(), s.keys, s.n * 8 * t.key_words, hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        for (uint64_t r = 0; r < s.n; ++r) {
+            Key k = t.key_words == 2 ? Key{s.hkeys[2 * r], s.hkeys[2 * r + 1]} : Key{0, s.hkeys[r]};
+            t.index[k] = Loc{b, r};
+        }
+    }
+    t.indexed = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel dispatch
+// ------------------------------------------------------------------------------------------
+template <int W, bool MASK, int TQ, int MODE>
+void launch_scan_nt(bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    if (nt) hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true>), grid, dim3(isk::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, false>), grid, dim3(isk::BLOCK), 0, st, p);
+}
+template <int W, bool MASK, int TQ>
+void launch_scan_mode(int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    if (mode == isk::MODE_COLLECT) launch_scan_nt<W, MASK, TQ, isk::MODE_COLLECT>(nt, grid, st, p);
+    else launch_scan_nt<W, MASK, TQ, isk::MODE_HIST>(nt, grid, st, p);
+}
+template <int W, bool MASK>
+void launch_scan_tq(int tq, int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    switch (tq) {
+        case 8: launch_scan_mode<W, MASK, 8>(mode, nt, grid, st, p); break;
+        case 32: launch_scan_mode<W, MASK, 32>(mode, nt, grid, st, p); break;
+        default: launch_scan_mode<W, MASK, 16>(mode, nt, grid, st, p); break;
+    }
+}
+template <int W>
+void launch_scan_mask(bool mask, int tq, int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    if (mask) launch_scan_tq<W, true>(tq, mode, nt, grid, st, p);
+    else launch_scan_tq<W, false>(tq, mode, nt, grid, st, p);
+}
+void launch_scan(int W, bool mask, int tq, int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    switch (W) {
+        case 1: launch_scan_mask<1>(mask, tq, mode, nt, grid, st, p); break;
+        case 2: launch_scan_mask<2>(mask, tq, mode, nt, grid, st, p); break;
+        case 3: launch_scan_mask<3>(mask, tq, mode, nt, grid, st, p); break;
+        default: launch_scan_mask<4>(mask, tq, mode, nt, grid, st, p); break;
+    }
+}
+int tile_rows_for(int W) { return W == 1 ? isk::tile_rows<1>() : W == 2 ? isk::tile_rows<2>() : W == 3 ? isk::tile_rows<3>() : isk::tile_rows<4>(); }
+
+uint32_t scan_grid_x(H* h, int W, uint64_t rows) {
+    const uint64_t tiles = rows / (uint64_t)tile_rows_for(W);
+    const uint64_t maxb = (uint64_t)h->cus * 8;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, maxb));
+}
+
+int event_pair(H* h, hipEvent_t& a, hipEvent_t& b) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t x, y;
+        HIPOK(hipEventCreate(&x));
+        HIPOK(hipEventCreate(&y));
+        h->ev_pool.emplace_back(x, y);
+    }
+    a = h->ev_pool[h->ev_used].first;
+    b = h->ev_pool[h->ev_used].second;
+    ++h->ev_used;
+    return 0;
+}
+
+// fold the recorded event pairs into stats.scan_ms (synchronises the stream)
+int drain_events(H* h) {
+    if (!h->ev_used) return 0;
+    HIPOK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        HIPOK(hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+        h->stats.scan_ms += ms;
+    }
+    h->ev_used = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// the search pipeline for one batch (<= QB_MAX) of equal-length queries
+// ------------------------------------------------------------------------------------------
+struct Job {
+    Segment* seg;
+    uint32_t pbytes;   // compared prefix in bytes
+    uint32_t W;        // words compared
+    bool mask;
+    uint64_t mask_last;
+};
+
+// d_out[nq*k] / d_out_cnt[nq] are device buffers.  hq: host query words [nq][max_words].
+int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbytes, uint32_t k,
+                 isk::Record* d_out, uint32_t* d_out_cnt) {
+    const int tq = h->tq;
+    const uint32_t nq_pad = (nq + tq - 1) / tq * tq;
+    const uint32_t groups = nq_pad / tq;
+
+    std::vector<Job> jobs;
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
+        Segment& s = t.seg[b];
+        if (!s.n) continue;
+        Job j;
+        j.seg = &s;
+        j.pbytes = t.metric == ISCCSEARCH_METRIC_NPHD ? std::min(b, qbytes) : b;
+        j.W = (j.pbytes + 7) / 8;
+        j.mask = (j.pbytes & 7) != 0;
+        j.mask_last = mask_for(j.pbytes);
+        jobs.push_back(j);
+    }
+    if (jobs.empty()) {
+        HIPOK(hipMemsetAsync(d_out_cnt, 0, nq * sizeof(uint32_t), h->stream));
+        return 0;
+    }
+
+    const uint32_t cap = std::max<uint32_t>(16384, 8 * k);
+    int rc;
+    if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;
+    if ((rc = h->d_bias.ensure(nq_pad))) return rc;
+    if ((rc = h->d_cnt.ensure(nq_pad))) return rc;
+    if ((rc = h->d_ghist.ensure((size_t)nq_pad * isk::HB))) return rc;
+    if ((rc = h->d_overflow.ensure(nq_pad))) return rc;
+    if ((rc = h->d_cand.ensure((size_t)nq_pad * cap))) return rc;
+    const bool multi = jobs.size() > 1;
+    if (multi) {
+        if ((rc = h->d_lists.ensure(jobs.size() * (size_t)nq * k))) return rc;
+        if ((rc = h->d_listcnt.ensure(jobs.size() * (size_t)nq))) return rc;
+    }
+
+    // stage queries: [nq_pad][4], padded words zero
+    std::vector<uint64_t> stage((size_t)nq_pad * 4, 0);
+    for (uint32_t q = 0; q < nq; ++q)
+        for (int w = 0; w < t.max_words; ++w) stage[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
+    HIPOK(hipMemcpyAsync(h->d_queries.p, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));   // `stage` is pageable host memory about to go out of scope
+    HIPOK(hipMemsetAsync(h->d_overflow.p, 0, nq_pad * sizeof(uint32_t), h->stream));
+
+    const uint32_t P = next_pow2(k);
+    const size_t sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
+
+    std::vector<uint32_t> job_overflow;
+    for (size_t ji = 0; ji < jobs.size(); ++ji) {
+        const Job& j = jobs[ji];
+        Segment& s = *j.seg;
+        isk::Record* out = multi ? h->d_lists.p + ji * (size_t)nq * k : d_out;
+        uint32_t* out_cnt = multi ? h->d_listcnt.p + ji * (size_t)nq : d_out_cnt;
+
+        // 1. bootstrap threshold from the first s0 rows
+        const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(4096, std::min<uint64_t>(65536, 64ull * k)));
+        isk::BootParams bp{};
+        for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
+        bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
+        hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
+
+        isk::ScanParams sp{};
+        for (uint32_t w = 0; w < j.W; ++w) sp.col[w] = s.col[w];
+        sp.queries = h->d_queries.p; sp.bias = h->d_bias.p; sp.cnt = h->d_cnt.p; sp.cand = h->d_cand.p;
+        sp.ghist = h->d_ghist.p; sp.cap = cap;
+        sp.mask_lo = (uint32_t)j.mask_last; sp.mask_hi = (uint32_t)(j.mask_last >> 32);
+
+        // 2. sample scan: tighten the threshold to the k-th smallest of the first `sample` rows
+        const uint64_t want = (s.n / 1024 + 1) * (uint64_t)k;      // ~ n*k/1024 rows -> ~1024 candidates per query
+        const uint64_t sample = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, want));
+        if (sample > s0) {
+            HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
+            sp.n_rows = sample;
+            launch_scan((int)j.W, j.mask, tq, isk::MODE_HIST, h->nontemporal, dim3(scan_grid_x(h, j.W, sample), groups), h->stream, sp);
+            isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, sample)};
+            hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
+            h->stats.sample_bytes += sample * 8 * j.W * groups;
+        }
+
+        // 3. the streaming pass: collect every row within the threshold
+        HIPOK(hipMemsetAsync(h->d_cnt.p, 0, nq_pad * sizeof(uint32_t), h->stream));
+        sp.n_rows = s.n;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
+        launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), groups), h->stream, sp);
+        if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+        h->stats.scan_launches += 1;
+        h->stats.scan_passes += groups;
+        h->stats.scan_bytes += s.n * 8 * j.W * groups;
+
+        // 4. exact select of the k best candidates per query
+        isk::SelectParams sl{};
+        sl.cnt = h->d_cnt.p; sl.cand = h->d_cand.p; sl.cap = cap; sl.keys = s.keys;
+        sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
+        sl.out = out; sl.out_count = out_cnt; sl.overflow = h->d_overflow.p; sl.k = k; sl.P = P;
+        sl.prefix_bits = j.pbytes * 8; sl.q_base = 0;
+        if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(nq), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+        else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(nq), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+        HIPOK(hipGetLastError());
+
+        // 5. overflow check (one small copy per job; almost always all zero)
+        h->h_overflow.resize(nq);
+        HIPOK(hipMemcpyAsync(h->h_overflow.data(), h->d_overflow.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        for (uint32_t q = 0; q < nq; ++q) {
+            if (!h->h_overflow[q]) continue;
+            // exact fallback for this query on this segment
+            h->stats.fallback_queries += 1;
+            if ((rc = h->d_misc.ensure(isk::HB + 8))) return rc;
+            uint32_t* d_fh = reinterpret_cast<uint32_t*>(h->d_misc.p);
+            HIPOK(hipMemsetAsync(d_fh, 0, isk::HB * sizeof(uint32_t), h->stream));
+            isk::FullHistParams fp{};
+            for (uint32_t w = 0; w < j.W; ++w) fp.col[w] = s.col[w];
+            fp.n_rows = s.n; fp.query = h->d_queries.p + (size_t)q * 4; fp.ghist = d_fh; fp.W = j.W; fp.mask_last = j.mask_last;
+            const uint32_t fgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + isk::BLOCK - 1) / isk::BLOCK, (uint64_t)h->cus * 8));
+            hipLaunchKernelGGL(isk::fullhist_kernel, dim3(fgrid), dim3(isk::BLOCK), 0, h->stream, fp);
+            uint32_t fh[isk::HB];
+            HIPOK(hipMemcpyAsync(fh, d_fh, sizeof fh, hipMemcpyDeviceToHost, h->stream));
+            HIPOK(hipStreamSynchronize(h->stream));
+            uint64_t cum = 0;
+            uint32_t tau = 256;
+            const uint64_t need = std::min<uint64_t>(k, s.n);
+            for (uint32_t b = 0; b < isk::NBINS; ++b) { cum += fh[b]; if (cum >= need) { tau = b; break; } }
+            // candidates with hamming <= tau: exactly `cum` rows, collected into a private buffer
+            if (cum > 0xFFFFFFFFull) return fail(-E2BIG, "tie class of %llu rows exceeds the fallback buffer", (unsigned long long)cum);
+            if ((rc = h->d_misc2.ensure((size_t)cum + 8))) return rc;
+            // rerun only the group holding q; every other slot of the group gets BIAS_NEVER
+            const uint32_t g = q / tq, ql = q - g * tq;
+            std::vector<uint32_t> hb(tq, isk::BIAS_NEVER);
+            hb[ql] = 0x7FFFFFFFu - tau;
+            HIPOK(hipMemcpyAsync(h->d_bias.p + (size_t)g * tq, hb.data(), tq * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)g * tq, 0, tq * sizeof(uint32_t), h->stream));
+            isk::ScanParams fsp = sp;
+            fsp.n_rows = s.n;
+            fsp.cap = (uint32_t)cum;
+            fsp.queries = h->d_queries.p + (size_t)g * tq * 4;
+            fsp.bias = h->d_bias.p + (size_t)g * tq;
+            fsp.cnt = h->d_cnt.p + (size_t)g * tq;
+            // slot ql of the group appends at cand[ql*cap + i]: bias the base so that lands at d_misc2[i]
+            fsp.cand = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)ql * fsp.cap * 8);
+            launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), 1), h->stream, fsp);
+            HIPOK(hipStreamSynchronize(h->stream));   // hb is pageable host memory
+            isk::SelectParams fsl = sl;
+            fsl.cnt = h->d_cnt.p; fsl.cap = fsp.cap; fsl.q_base = q;
+            fsl.cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)q * fsp.cap * 8);
+            // reset the overflow flag of q so a second overflow would be seen
+            HIPOK(hipMemsetAsync(h->d_overflow.p + q, 0, sizeof(uint32_t), h->stream));
+            if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(1), dim3(isk::BLOCK), sel_lds, h->stream, fsl);
+            else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(1), dim3(isk::BLOCK), sel_lds, h->stream, fsl);
+            HIPOK(hipGetLastError());
+            HIPOK(hipStreamSynchronize(h->stream));
+        }
+    }
+
+    if (multi) {
+        isk::MergeParams mp{h->d_lists.p, h->d_listcnt.p, d_out, d_out_cnt, (uint32_t)jobs.size(), nq, k};
+        hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
+    }
+    HIPOK(hipGetLastError());
+    return 0;
+}
+
+void unpack_records(const isk::Record* rec, const uint32_t* cnt, uint32_t nq, uint32_t k, int key_words,
+                    const uint32_t* dest_index /*nullable: original query index per row*/,
+                    uint64_t* out_keys, uint32_t* out_h, uint16_t* out_p, uint32_t* out_c) {
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t dq = dest_index ? dest_index[q] : q;
+        const uint32_t c = std::min(cnt[q], k);
+        out_c[dq] = c;
+        for (uint32_t i = 0; i < k; ++i) {
+            const size_t o = (size_t)dq * k + i;
+            if (i < c) {
+                const isk::Record& r = rec[(size_t)q * k + i];
+                if (key_words == 2) { out_keys[2 * o] = r.key_hi; out_keys[2 * o + 1] = r.key_lo; }
+                else out_keys[o] = r.key_lo;
+                out_h[o] = r.hamming;
+                out_p[o] = r.prefix_bits;
+            } else {
+                if (key_words == 2) { out_keys[2 * o] = 0; out_keys[2 * o + 1] = 0; }
+                else out_keys[o] = 0;
+                out_h[o] = 0;
+                out_p[o] = 0;
+            }
+        }
+    }
+}
+
+int check_query_lengths(const Table& t, uint32_t nq, const uint8_t* q_nbytes) {
+    if (t.metric == ISCCSEARCH_METRIC_HAMMING) {
+        if (q_nbytes)
+            for (uint32_t q = 0; q < nq; ++q)
+                if (q_nbytes[q] != t.max_bytes) return fail(-EINVAL, "query %u has %u bytes, table codes have %d", q, q_nbytes[q], t.max_bytes);
+        return 0;
+    }
+    if (!q_nbytes) return fail(-EINVAL, "q_nbytes is required for NPHD tables");
+    for (uint32_t q = 0; q < nq; ++q)
+        if (q_nbytes[q] < 1 || q_nbytes[q] > t.max_bytes) return fail(-EINVAL, "query %u length %u outside 1..%d bytes", q, q_nbytes[q], t.max_bytes);
+    return 0;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" {
+
+const char* isccsearch_last_error(void) { return g_last_error.c_str(); }
+
+int isccsearch_create(int device_id, isccsearch_handle** out) {
+    if (!out) return fail(-EINVAL, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(-ENODEV, "no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(-ENODEV, "device %d out of range (0..%d)", device_id, ndev - 1);
+    HIPOK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPOK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(-ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    std::unique_ptr<isccsearch_handle> h(new isccsearch_handle());
+    h->device = device_id;
+    h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPOK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    std::vector<uint16_t> rank;
+    build_rank_table(rank);
+    HIPOK(hipMalloc((void**)&h->d_rank, rank.size() * sizeof(uint16_t)));
+    HIPOK(hipMemcpy(h->d_rank, rank.data(), rank.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // the select kernel may need more than the default dynamic LDS for k near ISCCSEARCH_MAX_K
+    HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(&isk::select_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(&isk::select_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    h->stats.queries_per_pass = h->tq;
+    h->stats.compute_units = h->cus;
+    *out = h.release();
+    return 0;
+}
+
+int isccsearch_destroy(isccsearch_handle* h) {
+    if (!h) return 0;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        (void)hipSetDevice(h->device);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        for (auto& t : h->tables)
+            if (t) for (auto& s : t->seg) seg_free(s);
+        h->tables.clear();
+        h->d_queries.release(); h->d_bias.release(); h->d_cnt.release(); h->d_ghist.release();
+        h->d_overflow.release(); h->d_listcnt.release(); h->d_outcnt.release(); h->d_cand.release();
+        h->d_lists.release(); h->d_final.release(); h->d_misc.release(); h->d_misc2.release();
+        if (h->d_rank) (void)hipFree(h->d_rank);
+        for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+    return 0;
+}
+
+int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return fail(-EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!strcmp(name, "queries_per_pass")) {
+        if (value != 8 && value != 16 && value != 32) return fail(-EINVAL, "queries_per_pass must be 8, 16 or 32");
+        h->tq = (int)value;
+        h->stats.queries_per_pass = (uint32_t)value;
+        return 0;
+    }
+    if (!strcmp(name, "profile")) { h->profile = value != 0; return 0; }
+    if (!strcmp(name, "nontemporal")) { h->nontemporal = value != 0; return 0; }
+    return fail(-EINVAL, "unknown option '%s'", name);
+}
+
+int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset) {
+    if (!h || !out) return fail(-EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPOK(hipSetDevice(h->device));
+    int rc = drain_events(h);
+    if (rc) return rc;
+    *out = h->stats;
+    if (reset) {
+        const uint32_t tq = h->stats.queries_per_pass, cu = h->stats.compute_units;
+        h->stats = isccsearch_stats{};
+        h->stats.queries_per_pass = tq;
+        h->stats.compute_units = cu;
+    }
+    return 0;
+}
+
+int isccsearch_table_open(isccsearch_handle* h, int metric, int key_words, int max_bytes, uint32_t* table_id) {
+    if (!h || !table_id) return fail(-EINVAL, "bad arguments");
+    if (metric != ISCCSEARCH_METRIC_HAMMING && metric != ISCCSEARCH_METRIC_NPHD) return fail(-EINVAL, "unknown metric %d", metric);
+    if (key_words != 1 && key_words != 2) return fail(-EINVAL, "key_words must be 1 or 2");
+    if (max_bytes < 1 || max_bytes > ISCCSEARCH_MAX_BYTES) return fail(-EINVAL, "max_bytes must be 1..%d", ISCCSEARCH_MAX_BYTES);
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_ptr<Table> t(new Table());
+    t->open = true;
+    t->metric = metric;
+    t->key_words = key_words;
+    t->max_bytes = max_bytes;
+    t->max_words = (max_bytes + 7) / 8;
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) { t->seg[b].nbytes = b; t->seg[b].W = (b + 7) / 8; }
+    for (size_t i = 0; i < h->tables.size(); ++i)
+        if (!h->tables[i]) { h->tables[i] = std::move(t); *table_id = (uint32_t)i; return 0; }
+    h->tables.push_back(std::move(t));
+    *table_id = (uint32_t)(h->tables.size() - 1);
+    return 0;
+}
+
+int isccsearch_table_drop(isccsearch_handle* h, uint32_t table) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* t;
+    int rc = get_table(h, table, t);
+    if (rc) return rc;
+    HIPOK(hipSetDevice(h->device));
+    HIPOK(hipStreamSynchronize(h->stream));
+    for (auto& s : t->seg) seg_free(s);
+    h->tables[table].reset();
+    return 0;
+}
+
+int isccsearch_reserve(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t rows) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* t;
+    int rc = get_table(h, table, t);
+    if (rc) return rc;
+    if (nbytes < 1 || nbytes > t->max_bytes) return fail(-EINVAL, "nbytes %d outside 1..%d", nbytes, t->max_bytes);
+    if (t->metric == ISCCSEARCH_METRIC_HAMMING && nbytes != t->max_bytes) return fail(-EINVAL, "Hamming tables hold %d-byte codes only", t->max_bytes);
+    HIPOK(hipSetDevice(h->device));
+    return seg_reserve(h, *t, t->seg[nbytes], rows);
+}
+
+uint64_t isccsearch_size(isccsearch_handle* h, uint32_t table) {
+    if (!h) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* t;
+    if (get_table(h, table, t)) return 0;
+    return t->total;
+}
+
+int isccsearch_add(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
+                   const uint64_t* code_words, const uint8_t* nbytes, uint32_t flags) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    if (!keys || !code_words) return fail(-EINVAL, "keys/code_words are NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    HIPOK(hipSetDevice(h->device));
+    const int KW = t.key_words, MW = t.max_words;
+    if (t.metric == ISCCSEARCH_METRIC_NPHD && !nbytes) return fail(-EINVAL, "nbytes is required for NPHD tables");
+    // validate lengths, count rows per segment
+    uint64_t per_seg[ISCCSEARCH_MAX_BYTES + 1] = {0};
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t b = nbytes ? nbytes[i] : (uint32_t)t.max_bytes;
+        if (b < 1 || b > (uint32_t)t.max_bytes) return fail(-EINVAL, "row %llu: code length %u outside 1..%d bytes", (unsigned long long)i, b, t.max_bytes);
+        if (t.metric == ISCCSEARCH_METRIC_HAMMING && b != (uint32_t)t.max_bytes) return fail(-EINVAL, "row %llu: Hamming table holds %d-byte codes, got %u", (unsigned long long)i, t.max_bytes, b);
+        per_seg[b]++;
+    }
+    const bool trusted = (flags & ISCCSEARCH_ADD_TRUSTED_UNIQUE) != 0;
+    if (!trusted) {
+        if ((rc = ensure_index(h, t))) return rc;
+        std::unordered_map<Key, int, KeyHash> seen;
+        seen.reserve((size_t)n);
+        for (uint64_t i = 0; i < n; ++i) {
+            Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
+            if (t.index.count(k) || !seen.emplace(k, 1).second)
+                return fail(-EEXIST, "key %016llx%016llx already present (row %llu of the batch)", (unsigned long long)k.hi, (unsigned long long)k.lo, (unsigned long long)i);
+        }
+    }
+    // grow segments
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b)
+        if (per_seg[b] && (rc = seg_reserve(h, t, t.seg[b], t.seg[b].n + per_seg[b]))) return rc;
+    // stage per segment (word-major) and copy
+    std::vector<uint64_t> stage, kstage;
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
+        const uint64_t m = per_seg[b];
+        if (!m) continue;
+        Segment& s = t.seg[b];
+        const bool direct = (m == n && MW == 1);   // single segment, one word: the caller's buffers are already column-shaped
+        const uint64_t* kp = keys;
+        if (direct) {
+            HIPOK(hipMemcpyAsync(s.col[0] + s.n, code_words, m * 8, hipMemcpyHostToDevice, h->stream));
+        } else {
+            stage.resize((size_t)m * s.W);
+            uint64_t j = 0;
+            const uint64_t lastmask = mask_for(b);
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint32_t bi = nbytes ? nbytes[i] : (uint32_t)t.max_bytes;
+                if (bi != b) continue;
+                for (uint32_t w = 0; w < s.W; ++w) {
+                    uint64_t v = code_words[i * MW + w];
+                    if (w == s.W - 1) v &= lastmask;
+                    stage[(size_t)w * m + j] = v;
+                }
+                ++j;
+            }
+            for (uint32_t w = 0; w < s.W; ++w)
+                HIPOK(hipMemcpyAsync(s.col[w] + s.n, stage.data() + (size_t)w * m, m * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        if (m != n) {
+            kstage.resize((size_t)m * KW);
+            uint64_t j = 0;
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint32_t bi = nbytes ? nbytes[i] : (uint32_t)t.max_bytes;
+                if (bi != b) continue;
+                for (int w = 0; w < KW; ++w) kstage[(size_t)j * KW + w] = keys[i * KW + w];
+                ++j;
+            }
+            kp = kstage.data();
+        }
+        HIPOK(hipMemcpyAsync(s.keys + s.n * KW, kp, m * 8 * KW, hipMemcpyHostToDevice, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        if (t.indexed) {
+            s.hkeys.insert(s.hkeys.end(), kp, kp + m * KW);
+            for (uint64_t r = 0; r < m; ++r) {
+                Key k = KW == 2 ? Key{kp[2 * r], kp[2 * r + 1]} : Key{0, kp[r]};
+                t.index[k] = Loc{b, s.n + r};
+            }
+        }
+        s.n += m;
+        t.total += m;
+    }
+    return 0;
+}
+
+int isccsearch_add_synthetic(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t n,
+                             uint64_t seed, uint64_t first_row, uint64_t key_base) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    if (nbytes < 1 || nbytes > t.max_bytes) return fail(-EINVAL, "nbytes %d outside 1..%d", nbytes, t.max_bytes);
+    if (t.metric == ISCCSEARCH_METRIC_HAMMING && nbytes != t.max_bytes) return fail(-EINVAL, "Hamming tables hold %d-byte codes only", t.max_bytes);
+    if (t.indexed) return fail(-EINVAL, "synthetic rows cannot be added to a table whose key index is built");
+    HIPOK(hipSetDevice(h->device));
+    Segment& s = t.seg[nbytes];
+    if ((rc = seg_reserve(h, t, s, s.n + n))) return rc;
+    isk::FillParams fp{};
+    for (uint32_t w = 0; w < s.W; ++w) fp.col[w] = s.col[w];
+    fp.keys = s.keys; fp.dst_row = s.n; fp.n = n; fp.seed = seed; fp.first_row = first_row; fp.key_base = key_base;
+    fp.W = s.W; fp.KW = (uint32_t)t.key_words; fp.mask_last = mask_for((uint32_t)nbytes);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + isk::BLOCK - 1) / isk::BLOCK, (uint64_t)h->cus * 16);
+    hipLaunchKernelGGL(isk::fill_kernel, dim3(grid), dim3(isk::BLOCK), 0, h->stream, fp);
+    HIPOK(hipGetLastError());
+    HIPOK(hipStreamSynchronize(h->stream));
+    s.n += n;
+    t.total += n;
+    return 0;
+}
+
+int isccsearch_remove(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys, uint64_t* n_removed) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n_removed) *n_removed = 0;
+    if (n == 0) return 0;
+    if (!keys) return fail(-EINVAL, "keys is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    HIPOK(hipSetDevice(h->device));
+    if ((rc = ensure_index(h, t))) return rc;
+    const int KW = t.key_words;
+    std::vector<uint64_t> moves[ISCCSEARCH_MAX_BYTES + 1];
+    uint64_t removed = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
+        auto it = t.index.find(k);
+        if (it == t.index.end()) continue;
+        const Loc loc = it->second;
+        Segment& s = t.seg[loc.seg];
+        const uint64_t last = s.n - 1;
+        t.index.erase(it);
+        if (loc.row != last) {
+            Key lk2 = KW == 2 ? Key{s.hkeys[2 * last], s.hkeys[2 * last + 1]} : Key{0, s.hkeys[last]};
+            for (int w = 0; w < KW; ++w) s.hkeys[loc.row * KW + w] = s.hkeys[last * KW + w];
+            t.index[lk2] = Loc{loc.seg, loc.row};
+            moves[loc.seg].push_back(loc.row);
+            moves[loc.seg].push_back(last);
+        }
+        s.hkeys.resize((size_t)last * KW);
+        s.n = last;
+        t.total--;
+        ++removed;
+    }
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
+        if (moves[b].empty()) continue;
+        Segment& s = t.seg[b];
+        if ((rc = h->d_misc.ensure(moves[b].size()))) return rc;
+        HIPOK(hipMemcpyAsync(h->d_misc.p, moves[b].data(), moves[b].size() * 8, hipMemcpyHostToDevice, h->stream));
+        isk::MoveParams mp{};
+        for (uint32_t w = 0; w < s.W; ++w) mp.col[w] = s.col[w];
+        mp.keys = s.keys; mp.moves = h->d_misc.p; mp.n_moves = moves[b].size() / 2; mp.W = s.W; mp.KW = (uint32_t)KW;
+        hipLaunchKernelGGL(isk::move_rows_kernel, dim3(1), dim3(64), 0, h->stream, mp);
+        HIPOK(hipGetLastError());
+        HIPOK(hipStreamSynchronize(h->stream));
+    }
+    if (n_removed) *n_removed = removed;
+    return 0;
+}
+
+int isccsearch_contains(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys, uint8_t* out_found) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    if (!keys || !out_found) return fail(-EINVAL, "keys/out_found are NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    HIPOK(hipSetDevice(h->device));
+    if ((rc = ensure_index(h, *tp))) return rc;
+    const int KW = tp->key_words;
+    for (uint64_t i = 0; i < n; ++i) {
+        Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
+        out_found[i] = tp->index.count(k) ? 1 : 0;
+    }
+    return 0;
+}
+
+int isccsearch_get(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
+                   uint64_t* out_words, uint8_t* out_nbytes) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    if (!keys || !out_words || !out_nbytes) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    HIPOK(hipSetDevice(h->device));
+    if ((rc = ensure_index(h, t))) return rc;
+    const int KW = t.key_words, MW = t.max_words;
+    memset(out_words, 0, (size_t)n * MW * 8);
+    memset(out_nbytes, 0, (size_t)n);
+    std::vector<uint64_t> rows[ISCCSEARCH_MAX_BYTES + 1], dest[ISCCSEARCH_MAX_BYTES + 1];
+    for (uint64_t i = 0; i < n; ++i) {
+        Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
+        auto it = t.index.find(k);
+        if (it == t.index.end()) continue;
+        rows[it->second.seg].push_back(it->second.row);
+        dest[it->second.seg].push_back(i);
+        out_nbytes[i] = (uint8_t)it->second.seg;
+    }
+    std::vector<uint64_t> tmp;
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
+        if (rows[b].empty()) continue;
+        Segment& s = t.seg[b];
+        const uint64_t m = rows[b].size();
+        if ((rc = h->d_misc.ensure(m))) return rc;
+        if ((rc = h->d_misc2.ensure(m * s.W))) return rc;
+        HIPOK(hipMemcpyAsync(h->d_misc.p, rows[b].data(), m * 8, hipMemcpyHostToDevice, h->stream));
+        isk::GatherParams gp{};
+        for (uint32_t w = 0; w < s.W; ++w) gp.col[w] = s.col[w];
+        gp.rows = h->d_misc.p; gp.out = h->d_misc2.p; gp.n = m; gp.W = s.W;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((m + isk::BLOCK - 1) / isk::BLOCK, 1024);
+        hipLaunchKernelGGL(isk::gather_rows_kernel, dim3(grid), dim3(isk::BLOCK), 0, h->stream, gp);
+        HIPOK(hipGetLastError());
+        tmp.resize(m * s.W);
+        HIPOK(hipMemcpyAsync(tmp.data(), h->d_misc2.p, m * s.W * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        for (uint64_t i = 0; i < m; ++i)
+            for (uint32_t w = 0; w < s.W; ++w) out_words[dest[b][i] * MW + w] = tmp[i * s.W + w];
+    }
+    return 0;
+}
+
+int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                      const uint8_t* q_nbytes, uint32_t k,
+                      uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (k < 1) return fail(-EINVAL, "`count` must be >= 1");
+    if (k > ISCCSEARCH_MAX_K) return fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", k, ISCCSEARCH_MAX_K);
+    if (nq == 0) return 0;
+    if (!q_words || !out_keys || !out_hamming || !out_prefix_bits || !out_count) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    if ((rc = check_query_lengths(t, nq, q_nbytes))) return rc;
+    HIPOK(hipSetDevice(h->device));
+    h->stats.searches += 1;
+    h->stats.queries += nq;
+
+    // group queries by byte length (NPHD prefix length differs per class)
+    std::vector<uint32_t> order(nq);
+    for (uint32_t q = 0; q < nq; ++q) order[q] = q;
+    auto qlen = [&](uint32_t q) -> uint32_t { return (t.metric == ISCCSEARCH_METRIC_NPHD) ? q_nbytes[q] : (uint32_t)t.max_bytes; };
+    if (t.metric == ISCCSEARCH_METRIC_NPHD)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return q_nbytes[a] < q_nbytes[b]; });
+
+    std::vector<uint64_t> hq;
+    uint32_t pos = 0;
+    while (pos < nq) {
+        const uint32_t len = qlen(order[pos]);
+        uint32_t end = pos;
+        while (end < nq && end - pos < QB_MAX && qlen(order[end]) == len) ++end;
+        const uint32_t m = end - pos;
+        hq.resize((size_t)m * t.max_words);
+        for (uint32_t i = 0; i < m; ++i)
+            memcpy(&hq[(size_t)i * t.max_words], q_words + (size_t)order[pos + i] * t.max_words, (size_t)t.max_words * 8);
+        if ((rc = h->d_final.ensure((size_t)m * k))) return rc;
+        if ((rc = h->d_outcnt.ensure(m))) return rc;
+        if ((rc = search_batch(h, t, m, hq.data(), len, k, h->d_final.p, h->d_outcnt.p))) return rc;
+        h->h_final.resize((size_t)m * k);
+        h->h_cnt.resize(m);
+        HIPOK(hipMemcpyAsync(h->h_final.data(), h->d_final.p, (size_t)m * k * sizeof(isk::Record), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipMemcpyAsync(h->h_cnt.data(), h->d_outcnt.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        unpack_records(h->h_final.data(), h->h_cnt.data(), m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
+        pos = end;
+    }
+    return 0;
+}
+
+int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                             const uint8_t* q_nbytes, uint32_t k, void* d_records, uint32_t* d_counts) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (k < 1) return fail(-EINVAL, "`count` must be >= 1");
+    if (k > ISCCSEARCH_MAX_K) return fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", k, ISCCSEARCH_MAX_K);
+    if (nq == 0) return 0;
+    if (!q_words || !d_records || !d_counts) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    if ((rc = check_query_lengths(t, nq, q_nbytes))) return rc;
+    uint32_t len = (uint32_t)t.max_bytes;
+    if (t.metric == ISCCSEARCH_METRIC_NPHD) {
+        len = q_nbytes[0];
+        for (uint32_t q = 1; q < nq; ++q)
+            if (q_nbytes[q] != len) return fail(-EINVAL, "search_device needs queries of one byte length (query %u differs)", q);
+    }
+    HIPOK(hipSetDevice(h->device));
+    h->stats.searches += 1;
+    h->stats.queries += nq;
+    isk::Record* out = static_cast<isk::Record*>(d_records);
+    for (uint32_t pos = 0; pos < nq; pos += QB_MAX) {
+        const uint32_t m = std::min<uint32_t>(QB_MAX, nq - pos);
+        if ((rc = search_batch(h, t, m, q_words + (size_t)pos * t.max_words, len, k, out + (size_t)pos * k, d_counts + pos))) return rc;
+    }
+    HIPOK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
+                            const void* d_records, const uint32_t* d_counts,
+                            uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (nq == 0) return 0;
+    if (n_lists < 1 || k < 1 || k > ISCCSEARCH_MAX_K || (key_words != 1 && key_words != 2)) return fail(-EINVAL, "bad arguments");
+    if (!d_records || !d_counts || !out_keys || !out_hamming || !out_prefix_bits || !out_count) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPOK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->d_final.ensure((size_t)nq * k))) return rc;
+    if ((rc = h->d_outcnt.ensure(nq))) return rc;
+    isk::MergeParams mp{static_cast<const isk::Record*>(d_records), d_counts, h->d_final.p, h->d_outcnt.p, n_lists, nq, k};
+    hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
+    HIPOK(hipGetLastError());
+    h->h_final.resize((size_t)nq * k);
+    h->h_cnt.resize(nq);
+    HIPOK(hipMemcpyAsync(h->h_final.data(), h->d_final.p, (size_t)nq * k * sizeof(isk::Record), hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipMemcpyAsync(h->h_cnt.data(), h->d_outcnt.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    unpack_records(h->h_final.data(), h->h_cnt.data(), nq, k, key_words, nullptr, out_keys, out_hamming, out_prefix_bits, out_count);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,631 @@
+// kernels.hip.h -- gfx950 (MI355X, CDNA4) device code of the brute-force Hamming / NPHD k-NN path.
+//
+// What is computed (reference: docs/explanation/similarity-search.md:24-29, call sites
+// iscc_search/indexes/usearch/index.py:2037 and iscc_search/indexes/simprint/usearch_core.py:165):
+// for every query the k stored codes with the smallest (hamming over the common prefix, key).
+//
+// Data layout: a table is split into SEGMENTS by code length in bytes; inside a
+// segment all codes have the same length, so a (query class, segment) pass is a FIXED-length
+// Hamming scan over W = ceil(p/8) 64-bit words, p = min(query bytes, segment bytes).  Codes are
+// stored structure-of-arrays by word: col[w][row] (uint64, big-endian packed), keys[row*KW].
+//
+// Kernels
+//   boot_kernel    threshold bootstrap: exact histogram of the first S0 rows -> per-query bias
+//   scan_kernel    THE hot kernel: streams col[0..W) once per group of TQ queries; queries and
+//                  thresholds live in SGPRs; per (row, query) 2 v_xor + 2 v_bcnt per word and half a
+//                  v_min3; a lane leaves the streaming loop only when one of its rows beats a
+//                  threshold (MODE_HIST: count it, MODE_COLLECT: append (hamming,row) to the
+//                  query's candidate list)
+//   pick_kernel    threshold from the sample histogram
+//   select_kernel  per query: exact radix select over (hamming, key) of the candidates, bitonic
+//                  sort of the k winners in LDS, emit records
+//   fullhist_kernel exact histogram of one query over a whole segment (overflow fallback)
+//   merge_kernel   k-way merge of sorted record lists (segments of a table, shards of a node)
+//   plus small utilities (synthetic fill, row moves, row gathers)
+//
+// No MFMA: this is integer bit work bound by HBM reads (roofline in DESIGN.md section 4).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace isk {
+
+constexpr int BLOCK = 256;            // threads per workgroup = 4 waves of 64
+constexpr uint32_t HB = 264;          // histogram stride per query (bins 0..256 used)
+constexpr uint32_t NBINS = 257;       // hamming distance 0..256
+constexpr uint32_t BIT31 = 0x80000000u;
+constexpr uint32_t BIAS_NEVER = 0x80000000u;  // bias + h always has bit 31 set: never a candidate
+constexpr int MODE_COLLECT = 0;
+constexpr int MODE_HIST = 1;
+
+struct Record {            // == isccsearch_record (24 bytes)
+    uint64_t key_hi;
+    uint64_t key_lo;
+    uint32_t dist_rank;
+    uint16_t hamming;
+    uint16_t prefix_bits;
+};
+static_assert(sizeof(Record) == 24, "record layout");
+
+// rows per thread per tile: every thread issues U 16-byte loads per column (2 rows each)
+template <int W> struct TileCfg { static constexpr int U = (W == 1) ? 4 : (W == 2 ? 2 : 1); };
+template <int W> constexpr int tile_rows() { return BLOCK * 2 * TileCfg<W>::U; }
+
+struct ScanParams {
+    const uint64_t* col[4];   // segment columns (word-major)
+    uint64_t n_rows;          // rows [0, n_rows) are scanned
+    const uint64_t* queries;  // [nq_pad][4] big-endian packed query words
+    const uint32_t* bias;     // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries)
+    uint32_t* cnt;            // [nq_pad] candidates appended so far          (MODE_COLLECT)
+    uint64_t* cand;           // [nq_pad][cap] (hamming << 48) | row          (MODE_COLLECT)
+    uint32_t* ghist;          // [nq_pad][HB] histogram of hamming <= tau     (MODE_HIST)
+    uint32_t cap;
+    uint32_t mask_lo, mask_hi;  // mask of the last compared word (partial-word prefixes)
+};
+
+__device__ __forceinline__ uint32_t bcnt(uint32_t x, uint32_t acc) {
+    return (uint32_t)__builtin_popcount(x) + acc;   // cold paths: let the compiler pick the form
+}
+// Hot-path forms.  Left alone hipcc reassociates popc(x)+popc(y)+bias into 2 x v_bcnt(.., 0) +
+// v_add3 and splits the row-pair minimum into v_min + v_min3 (5.75 VALU ops per (row, query) pair
+// instead of 4.5).  An EMPTY asm statement on the running value stops the reassociation while
+// instruction selection still folds popc(x)+acc into one v_bcnt_u32_b32 and the two mins into one
+// v_min3_u32 (a non-empty asm makes the hazard recogniser pad with s_nop).
+__device__ __forceinline__ uint32_t pin(uint32_t v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t bcnt_s(uint32_t x, uint32_t acc_sgpr) { return pin((uint32_t)__builtin_popcount(x) + acc_sgpr); }
+__device__ __forceinline__ uint32_t bcnt_v(uint32_t x, uint32_t acc) { return (uint32_t)__builtin_popcount(x) + acc; }
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return pin(min(min(a, b), c)); }
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte global load: .x/.y = row r (lo, hi), .z/.w = row r+1
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load16(const uint64_t* p) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+
+template <int MODE>
+__device__ __forceinline__ void emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
+    if constexpr (MODE == MODE_COLLECT) {
+        const uint32_t slot = atomicAdd(&p.cnt[qi], 1u);
+        if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)h << 48) | row;
+    } else {
+        atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan_kernel<W, MASK, TQ, MODE, NT>
+//   grid = (blocks_x, query_groups); block = 256.  Group g holds queries [g*TQ, (g+1)*TQ).
+//   Fast path per tile: U*W coalesced 16-byte loads per lane, then for every query
+//       acc = bias_q; acc = bcnt(row_lo ^ q_lo, acc); acc = bcnt(row_hi ^ q_hi, acc)   (per word)
+//   so acc < 2^31  <=>  hamming <= tau_q, and one v_min3 folds two rows into the lane's running
+//   minimum.  Only lanes whose minimum has bit 31 clear enter the (rare) emit path.
+// ---------------------------------------------------------------------------------------------
+template <int W, bool MASK, int TQ, int MODE, bool NT>
+__global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
+    constexpr int U = TileCfg<W>::U;
+    constexpr int TILE = BLOCK * 2 * U;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q0 = blockIdx.y * TQ;
+
+    // queries and biases -> SGPRs (uniform addresses: scalar loads)
+    uint32_t qlo[TQ][W], qhi[TQ][W], bias[TQ];
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+        bias[q] = sgpr(p.bias[q0 + q]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t v = p.queries[(uint64_t)(q0 + q) * 4 + w];
+            qlo[q][w] = sgpr((uint32_t)v);
+            qhi[q][w] = sgpr((uint32_t)(v >> 32));
+        }
+    }
+    const uint32_t mlo = sgpr(p.mask_lo), mhi = sgpr(p.mask_hi);
+
+    const uint64_t n_full = p.n_rows / TILE;
+    // per-lane byte offsets inside a tile (constant over the loop); the tile base stays scalar
+    uint32_t voff[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) voff[u] = tid * 16u + (uint32_t)u * (BLOCK * 16u);
+    for (uint64_t tile = blockIdx.x; tile < n_full; tile += gridDim.x) {
+        const uint64_t base = tile * TILE + (uint64_t)tid * 2;
+        u32x4 v[U][W];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const char* tb = reinterpret_cast<const char*>(p.col[w]) + tile * (uint64_t)(TILE * 8);
+                v[u][w] = load16<NT>(reinterpret_cast<const uint64_t*>(tb + voff[u]));
+            }
+
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t a0, a1;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uint32_t x0 = v[u][w].x ^ qlo[q][w], y0 = v[u][w].y ^ qhi[q][w];
+                    uint32_t x1 = v[u][w].z ^ qlo[q][w], y1 = v[u][w].w ^ qhi[q][w];
+                    if (MASK && w == W - 1) { x0 &= mlo; y0 &= mhi; x1 &= mlo; y1 &= mhi; }
+                    if (w == 0) { a0 = bcnt_s(x0, bias[q]); a1 = bcnt_s(x1, bias[q]); }
+                    else { a0 = bcnt_v(x0, a0); a1 = bcnt_v(x1, a1); }
+                    a0 = bcnt_v(y0, a0);
+                    a1 = bcnt_v(y1, a1);
+                }
+                m = min3u(m, a0, a1);
+            }
+        }
+        if ((int32_t)m >= 0) {
+            // rare: at least one (row, query) pair of this lane is within its threshold
+#pragma unroll 1
+            for (int q = 0; q < TQ; ++q) {
+                const uint32_t b = p.bias[q0 + q];
+                uint32_t sl[W], sh[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint64_t qq = p.queries[(uint64_t)(q0 + q) * 4 + w];
+                    sl[w] = (uint32_t)qq; sh[w] = (uint32_t)(qq >> 32);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t a0 = b, a1 = b;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        uint32_t x0 = v[u][w].x ^ sl[w], y0 = v[u][w].y ^ sh[w];
+                        uint32_t x1 = v[u][w].z ^ sl[w], y1 = v[u][w].w ^ sh[w];
+                        if (MASK && w == W - 1) { x0 &= mlo; y0 &= mhi; x1 &= mlo; y1 &= mhi; }
+                        a0 = bcnt(y0, bcnt(x0, a0));
+                        a1 = bcnt(y1, bcnt(x1, a1));
+                    }
+                    const uint64_t row = base + (uint64_t)u * (BLOCK * 2);
+                    if ((int32_t)a0 >= 0) emit<MODE>(p, q0 + q, a0 - b, row);
+                    if ((int32_t)a1 >= 0) emit<MODE>(p, q0 + q, a1 - b, row + 1);
+                }
+            }
+        }
+    }
+
+    // tail rows [n_full*TILE, n_rows): one row per thread, handled by the first block of the group
+    if (blockIdx.x == 0) {
+        for (uint64_t row = n_full * TILE + tid; row < p.n_rows; row += BLOCK) {
+            uint32_t lo[W], hi[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint64_t c = p.col[w][row];
+                lo[w] = (uint32_t)c; hi[w] = (uint32_t)(c >> 32);
+            }
+#pragma unroll 1
+            for (int q = 0; q < TQ; ++q) {
+                const uint32_t b = p.bias[q0 + q];
+                uint32_t a = b;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint64_t qq = p.queries[(uint64_t)(q0 + q) * 4 + w];
+                    uint32_t x = lo[w] ^ (uint32_t)qq, y = hi[w] ^ (uint32_t)(qq >> 32);
+                    if (MASK && w == W - 1) { x &= mlo; y &= mhi; }
+                    a = bcnt(y, bcnt(x, a));
+                }
+                if ((int32_t)a >= 0) emit<MODE>(p, q0 + q, a - b, row);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// find the first histogram bin where the running count reaches `need`  (wave 0 does the work)
+//   returns the bin in res[0] and the count strictly below it in res[1]; every thread gets both.
+//   nbins <= 320.  If the total is below `need` the last bin is returned.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_find_cut(const uint32_t* hist, uint32_t nbins, uint32_t need,
+                                               uint32_t* res, uint32_t& bin, uint32_t& less) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < 64) {
+        uint32_t c[5], s = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t b = tid * 5 + j;
+            c[j] = b < nbins ? hist[b] : 0u;
+            s += c[j];
+        }
+        uint32_t incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (tid >= (uint32_t)off) incl += t;
+        }
+        const uint32_t excl = incl - s;
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (tid == 0 && total < need) {          // not enough entries: take everything
+            uint32_t last = 0, run = 0, below = 0;
+            for (uint32_t b = 0; b < nbins; ++b) { if (hist[b]) { last = b; below = run; } run += hist[b]; }
+            res[0] = last; res[1] = below;
+        }
+        if (total >= need && excl < need && need <= incl) {
+            uint32_t run = excl;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (run + c[j] >= need) { res[0] = tid * 5 + j; res[1] = run; break; }
+                run += c[j];
+            }
+        }
+    }
+    __syncthreads();
+    bin = res[0];
+    less = res[1];
+    __syncthreads();
+}
+
+struct BootParams {
+    const uint64_t* col[4];
+    const uint64_t* queries;  // [nq_pad][4]
+    uint32_t* bias;           // [nq_pad] out
+    uint64_t s0;              // rows [0, s0) are sampled (s0 >= 1)
+    uint32_t nq;              // real queries; blocks q >= nq write BIAS_NEVER
+    uint32_t k;
+    uint32_t W;
+    uint64_t mask_last;
+};
+
+// one block per (padded) query: exact histogram over the first s0 rows -> tau0 = k-th smallest
+__global__ __launch_bounds__(BLOCK) void boot_kernel(const BootParams p) {
+    __shared__ uint32_t hist[320];
+    __shared__ uint32_t res[2];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= p.nq) {
+        if (tid == 0) p.bias[q] = BIAS_NEVER;
+        return;
+    }
+    for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = 0;
+    __syncthreads();
+    uint64_t qw[4];
+    for (uint32_t w = 0; w < 4; ++w) qw[w] = w < p.W ? p.queries[(uint64_t)q * 4 + w] : 0;
+    for (uint64_t r = tid; r < p.s0; r += BLOCK) {
+        uint32_t h = 0;
+        for (uint32_t w = 0; w < p.W; ++w) {
+            uint64_t x = p.col[w][r] ^ qw[w];
+            if (w == p.W - 1) x &= p.mask_last;
+            h += (uint32_t)__builtin_popcountll(x);
+        }
+        atomicAdd(&hist[h], 1u);
+    }
+    __syncthreads();
+    const uint32_t need = p.k < p.s0 ? p.k : (uint32_t)p.s0;
+    uint32_t bin, less;
+    block_find_cut(hist, NBINS, need, res, bin, less);
+    if (tid == 0) p.bias[q] = 0x7FFFFFFFu - bin;
+}
+
+struct PickParams {
+    const uint32_t* ghist;   // [nq_pad][HB]
+    uint32_t* bias;          // [nq_pad] in/out
+    uint32_t nq;
+    uint32_t need;           // min(k, sample rows)
+};
+
+// one block per query: tau1 = first bin of the sample histogram where the running count >= need
+__global__ __launch_bounds__(BLOCK) void pick_kernel(const PickParams p) {
+    __shared__ uint32_t hist[320];
+    __shared__ uint32_t res[2];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (q >= p.nq) return;
+    for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = i < NBINS ? p.ghist[(uint64_t)q * HB + i] : 0u;
+    __syncthreads();
+    uint32_t bin, less;
+    block_find_cut(hist, NBINS, p.need, res, bin, less);
+    // never loosen the bootstrap threshold (the sample histogram only holds bins <= tau0)
+    const uint32_t tau0 = 0x7FFFFFFFu - p.bias[q];
+    if (tid == 0) p.bias[q] = 0x7FFFFFFFu - (bin < tau0 ? bin : tau0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// select_kernel<KW>: one block per query.  Exact top-k of the candidate list under (hamming, key).
+//   1. histogram of hamming over the candidates -> cut h*, `less` = candidates below it
+//   2. tie class h == h*: MSB-first radix select on the key (8 bits per pass) until the r smallest
+//      keys of the class are pinned down
+//   3. compact the keff winners into LDS, bitonic sort by (hamming, key_hi, key_lo), emit records
+// dynamic LDS: sh[P] u32 | pad | klo[P] u64 | khi[P] u64 (KW == 2)
+// ---------------------------------------------------------------------------------------------
+struct SelectParams {
+    const uint32_t* cnt;      // [nq_pad]
+    const uint64_t* cand;     // [nq_pad][cap]
+    uint64_t cap;
+    const uint64_t* keys;     // segment key column [rows*KW]
+    const uint16_t* rank;     // [257] hamming -> order-preserving distance rank for this prefix
+    Record* out;              // [nq][k]
+    uint32_t* out_count;      // [nq]
+    uint32_t* overflow;       // [nq] set to 1 when the candidate list overflowed
+    uint32_t k;
+    uint32_t P;               // power of two >= min(k, cap)
+    uint32_t prefix_bits;
+    uint32_t q_base;          // block b serves query q_base + b
+};
+
+template <int KW>
+__device__ __forceinline__ void load_key(const uint64_t* keys, uint64_t row, uint64_t& hi, uint64_t& lo) {
+    if constexpr (KW == 2) { hi = keys[2 * row]; lo = keys[2 * row + 1]; }
+    else { hi = 0; lo = keys[row]; }
+}
+// digit d (0 = most significant byte) of a KW-word key
+template <int KW>
+__device__ __forceinline__ uint32_t key_digit(uint64_t hi, uint64_t lo, int d) {
+    if constexpr (KW == 2) return d < 8 ? (uint32_t)(hi >> (56 - 8 * d)) & 255u : (uint32_t)(lo >> (56 - 8 * (d - 8))) & 255u;
+    else return (uint32_t)(lo >> (56 - 8 * d)) & 255u;
+}
+// the key with everything below its first d bytes cleared
+template <int KW>
+__device__ __forceinline__ void key_top(uint64_t hi, uint64_t lo, int d, uint64_t& thi, uint64_t& tlo) {
+    if constexpr (KW == 2) {
+        if (d >= 16) { thi = hi; tlo = lo; }
+        else if (d >= 8) { thi = hi; tlo = d == 8 ? 0 : lo & (~0ULL << (64 - 8 * (d - 8))); }
+        else { thi = d == 0 ? 0 : hi & (~0ULL << (64 - 8 * d)); tlo = 0; }
+    } else {
+        thi = 0;
+        tlo = d >= 8 ? lo : (d == 0 ? 0 : lo & (~0ULL << (64 - 8 * d)));
+    }
+}
+
+template <int KW>
+__global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t hist[320];
+    __shared__ uint32_t res[2];
+    __shared__ uint32_t n_out;
+    const uint32_t P = p.P;
+    uint32_t* sh = reinterpret_cast<uint32_t*>(smem);
+    uint64_t* sklo = reinterpret_cast<uint64_t*>(smem + (((size_t)P * 4 + 15) & ~(size_t)15));
+    uint64_t* skhi = sklo + P;   // only touched when KW == 2
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = p.q_base + blockIdx.x;
+    const uint32_t total = p.cnt[q];
+    if (total > p.cap) {             // candidate list overflowed: host reruns this query exactly
+        if (tid == 0) { p.overflow[q] = 1; p.out_count[q] = 0; }
+        return;
+    }
+    const uint64_t* cand = p.cand + (uint64_t)q * p.cap;
+    const uint32_t keff = p.k < total ? p.k : total;
+    if (keff == 0) {
+        if (tid == 0) p.out_count[q] = 0;
+        return;
+    }
+
+    // 1. cut on the hamming distance
+    for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = 0;
+    if (tid == 0) n_out = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < total; i += BLOCK) atomicAdd(&hist[(uint32_t)(cand[i] >> 48)], 1u);
+    __syncthreads();
+    uint32_t hstar, less;
+    block_find_cut(hist, NBINS, keff, res, hstar, less);
+    uint32_t tie = hist[hstar];
+    uint32_t r = keff - less;            // 1 <= r <= tie
+    __syncthreads();
+
+    // 2. radix select on the key inside the tie class
+    uint64_t phi = 0, plo = 0;           // selected key prefix (first d bytes)
+    int d = 0;
+    while (r < tie && d < KW * 8) {
+        for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += BLOCK) {
+            const uint64_t c = cand[i];
+            if ((uint32_t)(c >> 48) != hstar) continue;
+            uint64_t khi, klo, thi, tlo;
+            load_key<KW>(p.keys, c & 0xFFFFFFFFFFFFULL, khi, klo);
+            key_top<KW>(khi, klo, d, thi, tlo);
+            if (thi == phi && tlo == plo) atomicAdd(&hist[key_digit<KW>(khi, klo, d)], 1u);
+        }
+        __syncthreads();
+        uint32_t b, below;
+        block_find_cut(hist, 256, r, res, b, below);
+        tie = hist[b];
+        r -= below;
+        if (KW == 2 && d < 8) phi |= (uint64_t)b << (56 - 8 * d);
+        else plo |= (uint64_t)b << (56 - 8 * (KW == 2 ? d - 8 : d));
+        ++d;
+        __syncthreads();
+    }
+    // winners: hamming < h*, or hamming == h* and top-d key bytes <= selected prefix
+    // (when the loop stopped with r == tie every key sharing the prefix is taken)
+
+    // 3. compact
+    for (uint32_t i = tid; i < total; i += BLOCK) {
+        const uint64_t c = cand[i];
+        const uint32_t h = (uint32_t)(c >> 48);
+        if (h > hstar) continue;
+        uint64_t khi, klo;
+        load_key<KW>(p.keys, c & 0xFFFFFFFFFFFFULL, khi, klo);
+        if (h == hstar) {
+            uint64_t thi, tlo;
+            key_top<KW>(khi, klo, d, thi, tlo);
+            if (thi > phi || (thi == phi && tlo > plo)) continue;
+        }
+        const uint32_t pos = atomicAdd(&n_out, 1u);
+        if (pos < P) { sh[pos] = h; sklo[pos] = klo; if (KW == 2) skhi[pos] = khi; }
+    }
+    __syncthreads();
+    const uint32_t got = n_out < P ? n_out : P;     // == keff when keys are unique
+    for (uint32_t i = got + tid; i < P; i += BLOCK) { sh[i] = 0xFFFFFFFFu; sklo[i] = ~0ULL; if (KW == 2) skhi[i] = ~0ULL; }
+    __syncthreads();
+
+    // bitonic sort ascending by (h, khi, klo)
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = tid; i < (P >> 1); i += BLOCK) {
+                const uint32_t lo_i = 2 * i - (i & (stride - 1));
+                const uint32_t hi_i = lo_i + stride;
+                const bool up = (lo_i & size) == 0;
+                const uint32_t ha = sh[lo_i], hb = sh[hi_i];
+                const uint64_t la = sklo[lo_i], lb = sklo[hi_i];
+                uint64_t ka = 0, kb = 0;
+                if (KW == 2) { ka = skhi[lo_i]; kb = skhi[hi_i]; }
+                const bool a_gt_b = ha != hb ? ha > hb : (ka != kb ? ka > kb : la > lb);
+                if (a_gt_b == up) {
+                    sh[lo_i] = hb; sh[hi_i] = ha;
+                    sklo[lo_i] = lb; sklo[hi_i] = la;
+                    if (KW == 2) { skhi[lo_i] = kb; skhi[hi_i] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t nres = got < keff ? got : keff;
+    for (uint32_t i = tid; i < nres; i += BLOCK) {
+        Record rec;
+        rec.key_hi = KW == 2 ? skhi[i] : 0;
+        rec.key_lo = sklo[i];
+        rec.dist_rank = p.rank[sh[i]];
+        rec.hamming = (uint16_t)sh[i];
+        rec.prefix_bits = (uint16_t)p.prefix_bits;
+        p.out[(uint64_t)q * p.k + i] = rec;
+    }
+    if (tid == 0) p.out_count[q] = nres;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fullhist_kernel: exact hamming histogram of ONE query over a whole segment (overflow fallback)
+// ---------------------------------------------------------------------------------------------
+struct FullHistParams {
+    const uint64_t* col[4];
+    uint64_t n_rows;
+    const uint64_t* query;    // [4]
+    uint32_t* ghist;          // [HB] (zeroed by the host)
+    uint32_t W;
+    uint64_t mask_last;
+};
+__global__ __launch_bounds__(BLOCK) void fullhist_kernel(const FullHistParams p) {
+    __shared__ uint32_t hist[320];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = 0;
+    __syncthreads();
+    uint64_t qw[4];
+    for (uint32_t w = 0; w < 4; ++w) qw[w] = w < p.W ? p.query[w] : 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + tid; r < p.n_rows; r += (uint64_t)gridDim.x * BLOCK) {
+        uint32_t h = 0;
+        for (uint32_t w = 0; w < p.W; ++w) {
+            uint64_t x = p.col[w][r] ^ qw[w];
+            if (w == p.W - 1) x &= p.mask_last;
+            h += (uint32_t)__builtin_popcountll(x);
+        }
+        atomicAdd(&hist[h], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < NBINS; i += BLOCK)
+        if (hist[i]) atomicAdd(&p.ghist[i], hist[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge_kernel: per query, k-way merge of n_lists record lists, each sorted by (dist_rank, key).
+//   rank of an element = its position in its own list + the number of elements of every other
+//   list that sort before it (binary search); ranks are distinct because keys are.
+// ---------------------------------------------------------------------------------------------
+struct MergeParams {
+    const Record* lists;      // [n_lists][nq][k]
+    const uint32_t* counts;   // [n_lists][nq]
+    Record* out;              // [nq][k]
+    uint32_t* out_count;      // [nq]
+    uint32_t n_lists, nq, k;
+};
+__device__ __forceinline__ bool rec_less(const Record& a, const Record& b) {
+    if (a.dist_rank != b.dist_rank) return a.dist_rank < b.dist_rank;
+    if (a.key_hi != b.key_hi) return a.key_hi < b.key_hi;
+    return a.key_lo < b.key_lo;
+}
+__global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams p) {
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    uint32_t total = 0;
+    for (uint32_t l = 0; l < p.n_lists; ++l) total += p.counts[(uint64_t)l * p.nq + q];
+    const uint32_t keff = total < p.k ? total : p.k;
+    for (uint32_t e = tid; e < p.n_lists * p.k; e += BLOCK) {
+        const uint32_t l = e / p.k, i = e % p.k;
+        const uint32_t cl = p.counts[(uint64_t)l * p.nq + q];
+        if (i >= cl) continue;
+        const Record me = p.lists[((uint64_t)l * p.nq + q) * p.k + i];
+        uint32_t rank = i;
+        for (uint32_t o = 0; o < p.n_lists && rank < keff; ++o) {
+            if (o == l) continue;
+            const Record* lst = p.lists + ((uint64_t)o * p.nq + q) * p.k;
+            uint32_t lo = 0, hi = p.counts[(uint64_t)o * p.nq + q];
+            // elements of list o sorting before `me`; an (impossible) exact tie goes to the lower list id
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const bool before = o < l ? !rec_less(me, lst[mid]) : rec_less(lst[mid], me);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < keff) p.out[(uint64_t)q * p.k + rank] = me;
+    }
+    if (tid == 0) p.out_count[q] = keff;
+}
+
+// ---------------------------------------------------------------------------------------------
+// utilities
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+struct FillParams {
+    uint64_t* col[4];
+    uint64_t* keys;
+    uint64_t dst_row;      // first destination row in the segment
+    uint64_t n;
+    uint64_t seed, first_row, key_base;
+    uint32_t W, KW;
+    uint64_t mask_last;    // codes shorter than W words keep zero padding
+};
+__global__ __launch_bounds__(BLOCK) void fill_kernel(const FillParams p) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < p.n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t src = p.first_row + i;
+        for (uint32_t w = 0; w < p.W; ++w) {
+            uint64_t v = splitmix64(p.seed + 4 * src + w);
+            if (w == p.W - 1) v &= p.mask_last;
+            p.col[w][p.dst_row + i] = v;
+        }
+        if (p.KW == 2) { p.keys[2 * (p.dst_row + i)] = 0; p.keys[2 * (p.dst_row + i) + 1] = p.key_base + src; }
+        else p.keys[p.dst_row + i] = p.key_base + src;
+    }
+}
+
+// sequential row moves (swap-with-last removal): lane c owns column c for every move, in order
+struct MoveParams {
+    uint64_t* col[4];
+    uint64_t* keys;
+    const uint64_t* moves;   // [n_moves][2] = (dst, src)
+    uint64_t n_moves;
+    uint32_t W, KW;
+};
+__global__ void move_rows_kernel(const MoveParams p) {
+    const uint32_t c = threadIdx.x;
+    if (c < p.W) {
+        uint64_t* col = p.col[c];
+        for (uint64_t m = 0; m < p.n_moves; ++m) col[p.moves[2 * m]] = col[p.moves[2 * m + 1]];
+    } else if (c < p.W + p.KW) {
+        const uint32_t kw = c - p.W;
+        for (uint64_t m = 0; m < p.n_moves; ++m) p.keys[p.moves[2 * m] * p.KW + kw] = p.keys[p.moves[2 * m + 1] * p.KW + kw];
+    }
+}
+
+struct GatherParams {
+    const uint64_t* col[4];
+    const uint64_t* rows;    // [n]
+    uint64_t* out;           // [n][W]
+    uint64_t n;
+    uint32_t W;
+};
+__global__ __launch_bounds__(BLOCK) void gather_rows_kernel(const GatherParams p) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < p.n; i += (uint64_t)gridDim.x * BLOCK)
+        for (uint32_t w = 0; w < p.W; ++w) p.out[i * p.W + w] = p.col[w][p.rows[i]];
+}
+
+}  // namespace isk

@@ -1,0 +1,279 @@
+"""
+numpy-level wrapper of the C-ABI: one ``HipEngine`` per GPU, ``HipTable`` per code table.
+
+This is the thinnest layer above ``include/isccsearch.h``; the reference-shaped objects
+(``HipNphdIndex`` ~ ``iscc_usearch.ShardedNphdIndex``, ``HipIndex128`` ~ ``ShardedIndex128``) live in
+``iscc_search_amd/nphd.py``.  Nothing here computes distances on the CPU.
+"""
+
+import ctypes
+import threading
+
+import numpy as np
+
+from iscc_search_amd import _lib
+
+
+def pack_bytes(codes, max_words):
+    # type: (list[bytes] | np.ndarray, int) -> tuple[np.ndarray, np.ndarray]
+    """
+    Pack codes big-endian into zero-padded uint64 words (the C-ABI layout).
+
+    :param codes: list of byte strings (any lengths 1..max_words*8) or a 2-D uint8 array (equal lengths)
+    :param max_words: words per row in the output
+    :return: (words uint64 [n, max_words], nbytes uint8 [n])
+    """
+    width = max_words * 8
+    if isinstance(codes, np.ndarray) and codes.ndim == 2:
+        arr = np.ascontiguousarray(codes, dtype=np.uint8)
+        n, nb = arr.shape
+        if not 1 <= nb <= width:
+            raise ValueError(f"code length {nb} bytes outside 1..{width}")
+        buf = np.zeros((n, width), dtype=np.uint8)
+        buf[:, :nb] = arr
+        lens = np.full(n, nb, dtype=np.uint8)
+    else:
+        n = len(codes)
+        buf = np.zeros((n, width), dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.uint8)
+        for i, c in enumerate(codes):
+            c = bytes(c) if not isinstance(c, np.ndarray) else c.astype(np.uint8).tobytes()
+            if not 1 <= len(c) <= width:
+                raise ValueError(f"code length {len(c)} bytes outside 1..{width}")
+            buf[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
+            lens[i] = len(c)
+    words = buf.view(">u8").astype(np.uint64).reshape(n, max_words)
+    return words, lens
+
+
+def unpack_words(words, nbytes):
+    # type: (np.ndarray, int) -> bytes
+    """Inverse of ``pack_bytes`` for one row."""
+    return np.ascontiguousarray(words, dtype=np.uint64).astype(">u8").tobytes()[:nbytes]
+
+
+class HipEngine:
+    """One engine handle = one GPU = one HIP stream (``isccsearch_create``)."""
+
+    def __init__(self, device_id=0):
+        # type: (int) -> None
+        self._lib = _lib.load_library()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.isccsearch_create(int(device_id), ctypes.byref(h)))
+        self._h = h
+        self.device_id = int(device_id)
+        self._lock = threading.Lock()
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError("engine is closed")
+        return self._h
+
+    def open_table(self, metric, key_words, max_bytes):
+        # type: (int, int, int) -> HipTable
+        tid = ctypes.c_uint32()
+        _lib.check(self._lib.isccsearch_table_open(self.handle, metric, key_words, max_bytes, ctypes.byref(tid)))
+        return HipTable(self, tid.value, metric, key_words, max_bytes)
+
+    def set_option(self, name, value):
+        # type: (str, int) -> None
+        _lib.check(self._lib.isccsearch_set_option(self.handle, name.encode(), int(value)))
+
+    def stats(self, reset=False):
+        # type: (bool) -> dict
+        st = _lib.Stats()
+        _lib.check(self._lib.isccsearch_stats_get(self.handle, ctypes.byref(st), 1 if reset else 0))
+        return st.as_dict()
+
+    def merge_device(self, n_lists, nq, k, key_words, d_records_ptr, d_counts_ptr):
+        # type: (int, int, int, int, int, int) -> tuple
+        """k-way merge of gathered per-shard results held in device memory (``isccsearch_merge_device``)."""
+        out = _alloc_out(nq, k, key_words)
+        _lib.check(
+            self._lib.isccsearch_merge_device(
+                self.handle, n_lists, nq, k, key_words, ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr),
+                _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32),
+                _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32),
+            )
+        )
+        return out
+
+    def close(self):
+        # type: () -> None
+        """Idempotent (``protocols/index.py:167-172``)."""
+        with self._lock:
+            if self._h is not None:
+                self._lib.isccsearch_destroy(self._h)
+                self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _alloc_out(nq, k, key_words):
+    shape = (nq, k, 2) if key_words == 2 else (nq, k)
+    return (
+        np.zeros(shape, dtype=np.uint64),
+        np.zeros((nq, k), dtype=np.uint32),
+        np.zeros((nq, k), dtype=np.uint16),
+        np.zeros(nq, dtype=np.uint32),
+    )
+
+
+class HipTable:
+    """A table of (key, code) rows resident in HBM."""
+
+    def __init__(self, engine, table_id, metric, key_words, max_bytes):
+        # type: (HipEngine, int, int, int, int) -> None
+        self.engine = engine
+        self.id = table_id
+        self.metric = metric
+        self.key_words = key_words
+        self.max_bytes = max_bytes
+        self.max_words = (max_bytes + 7) // 8
+        self._open = True
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        if self.key_words == 2:
+            if keys.ndim != 2 or keys.shape[1] != 2:
+                raise ValueError("128-bit keys must be shaped [n, 2] (hi, lo)")
+        elif keys.ndim != 1:
+            raise ValueError("64-bit keys must be shaped [n]")
+        return keys
+
+    def _words(self, words, n=None):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        if words.ndim != 2 or words.shape[1] != self.max_words:
+            raise ValueError(f"code words must be shaped [n, {self.max_words}]")
+        if n is not None and words.shape[0] != n:
+            raise ValueError("keys and codes differ in length")
+        return words
+
+    def _nbytes(self, nbytes, n):
+        if self.metric == _lib.METRIC_HAMMING:
+            if nbytes is not None and np.any(np.asarray(nbytes) != self.max_bytes):
+                raise ValueError(f"Hamming table holds {self.max_bytes}-byte codes only")
+            return None
+        if nbytes is None:
+            raise ValueError("nbytes is required for NPHD tables")
+        nbytes = np.ascontiguousarray(nbytes, dtype=np.uint8)
+        if nbytes.shape != (n,):
+            raise ValueError("nbytes must be shaped [n]")
+        return nbytes
+
+    # -- C-ABI calls -------------------------------------------------------------------------
+    def add(self, keys, words, nbytes=None, trusted_unique=False):
+        # type: (np.ndarray, np.ndarray, np.ndarray | None, bool) -> None
+        keys = self._keys(keys)
+        n = keys.shape[0]
+        if n == 0:
+            return
+        words = self._words(words, n)
+        nbytes = self._nbytes(nbytes, n)
+        flags = _lib.ADD_TRUSTED_UNIQUE if trusted_unique else 0
+        lib = self.engine._lib
+        _lib.check(
+            lib.isccsearch_add(
+                self.engine.handle, self.id, n, _lib.ptr(keys, ctypes.c_uint64), _lib.ptr(words, ctypes.c_uint64),
+                _lib.ptr(nbytes, ctypes.c_uint8), flags,
+            )
+        )
+
+    def add_synthetic(self, nbytes, n, seed, first_row=0, key_base=0):
+        # type: (int, int, int, int, int) -> None
+        lib = self.engine._lib
+        _lib.check(lib.isccsearch_add_synthetic(self.engine.handle, self.id, nbytes, n, seed & (2**64 - 1), first_row, key_base))
+
+    def reserve(self, nbytes, rows):
+        # type: (int, int) -> None
+        _lib.check(self.engine._lib.isccsearch_reserve(self.engine.handle, self.id, nbytes, rows))
+
+    def remove(self, keys):
+        # type: (np.ndarray) -> int
+        keys = self._keys(keys)
+        if keys.shape[0] == 0:
+            return 0
+        removed = ctypes.c_uint64()
+        _lib.check(
+            self.engine._lib.isccsearch_remove(
+                self.engine.handle, self.id, keys.shape[0], _lib.ptr(keys, ctypes.c_uint64), ctypes.byref(removed)
+            )
+        )
+        return int(removed.value)
+
+    def contains(self, keys):
+        # type: (np.ndarray) -> np.ndarray
+        keys = self._keys(keys)
+        out = np.zeros(keys.shape[0], dtype=np.uint8)
+        if keys.shape[0]:
+            _lib.check(
+                self.engine._lib.isccsearch_contains(
+                    self.engine.handle, self.id, keys.shape[0], _lib.ptr(keys, ctypes.c_uint64), _lib.ptr(out, ctypes.c_uint8)
+                )
+            )
+        return out.astype(bool)
+
+    def get(self, keys):
+        # type: (np.ndarray) -> tuple[np.ndarray, np.ndarray]
+        """Stored codes of ``keys``: (words [n, max_words], nbytes [n]; 0 = absent)."""
+        keys = self._keys(keys)
+        n = keys.shape[0]
+        words = np.zeros((n, self.max_words), dtype=np.uint64)
+        nb = np.zeros(n, dtype=np.uint8)
+        if n:
+            _lib.check(
+                self.engine._lib.isccsearch_get(
+                    self.engine.handle, self.id, n, _lib.ptr(keys, ctypes.c_uint64), _lib.ptr(words, ctypes.c_uint64),
+                    _lib.ptr(nb, ctypes.c_uint8),
+                )
+            )
+        return words, nb
+
+    @property
+    def size(self):
+        # type: () -> int
+        return int(self.engine._lib.isccsearch_size(self.engine.handle, self.id))
+
+    def search(self, q_words, q_nbytes, k):
+        # type: (np.ndarray, np.ndarray | None, int) -> tuple
+        """Exact top-k: (keys [nq, k(,2)], hamming [nq, k], prefix_bits [nq, k], count [nq])."""
+        q_words = self._words(q_words)
+        nq = q_words.shape[0]
+        if k < 1:
+            raise ValueError("`count` must be >= 1")
+        q_nbytes = self._nbytes(q_nbytes, nq)
+        out = _alloc_out(nq, k, self.key_words)
+        if nq:
+            _lib.check(
+                self.engine._lib.isccsearch_search(
+                    self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k,
+                    _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32),
+                    _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32),
+                )
+            )
+        return out
+
+    def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr):
+        # type: (np.ndarray, np.ndarray | None, int, int, int) -> None
+        """Same search, results left in caller-owned device memory (multi-GPU exchange)."""
+        q_words = self._words(q_words)
+        nq = q_words.shape[0]
+        q_nbytes = self._nbytes(q_nbytes, nq)
+        _lib.check(
+            self.engine._lib.isccsearch_search_device(
+                self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k,
+                ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr),
+            )
+        )
+
+    def drop(self):
+        # type: () -> None
+        if self._open and self.engine._h is not None:
+            _lib.check(self.engine._lib.isccsearch_table_drop(self.engine.handle, self.id))
+        self._open = False

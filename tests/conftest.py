@@ -1,0 +1,29 @@
+"""
+Test configuration.
+
+Markers:
+  gpu -- needs a real MI355X; run with ``pytest -m gpu`` on the GPU box.  Everything else runs on CPU.
+"""
+
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (gfx950) device")
+
+
+@pytest.fixture(scope="session")
+def hip_engine():
+    """One engine for the whole GPU session (a single process on the card)."""
+    from iscc_search_amd.engine import HipEngine
+
+    eng = HipEngine(0)
+    yield eng
+    eng.close()
