@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""
+bench.py -- queries/sec and achieved HBM GB/s of the brute-force 64-bit Hamming k=10 search.
+
+Workload (BASELINE.json `metric`): 100 M synthetic 64-bit codes resident in HBM, k = 10, batches of
+1 024 queries streamed as passes of T_q (=8) queries.  A "step" is one 1 024-query search through
+the C-ABI (threshold bootstrap + sample scan + streaming scan + select [+ all-gather + merge]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`;
+   one rank per GPU over RCCL; STRONG scaling: the 100 M rows are row-range sharded over the ranks,
+   every rank answers every query on its shard, ONE all-gather exchanges the per-shard top-k.)
+
+Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes of the streaming-scan
+launches (rows x 8 x words x query groups) / their summed device time, measured
+with HIP events on the library's own stream inside the timed region.  `cpu_baseline` = the oracle
+(CPU restatement, OpenMP) timed on the host cores over the same 100 M rows for a bounded number of
+queries (rank 0, N = 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED_CODES = 0x1511CC00
+SEED_Q = 0x1511CC02
+SEED_P = 0x1511CC03
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
+MASK64 = (1 << 64) - 1
+
+
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & MASK64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & MASK64
+    return x ^ (x >> 31)
+
+
+def make_queries(nq, rows, words):
+    """random queries; every 4th is a stored code with f in {0,1,3,7} low bits flipped."""
+    q = np.zeros((nq, words), dtype=np.uint64)
+    planted = {}
+    for j in range(nq):
+        if j % 4 == 0:
+            r = splitmix64(SEED_P + j) % rows
+            f = (0, 1, 3, 7)[(j // 4) % 4]
+            for w in range(words):
+                q[j, w] = splitmix64(SEED_CODES + 4 * r + w)
+            q[j, words - 1] ^= np.uint64(f)
+            planted[j] = (r, bin(f).count("1"))
+        else:
+            for w in range(words):
+                q[j, w] = splitmix64(SEED_Q + 4 * j + w)
+    return q, planted
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="total rows of the index (all ranks together)")
+    ap.add_argument("--queries", type=int, default=1024, help="queries per step")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--nbytes", type=int, default=8, help="code length in bytes (8 = 64-bit)")
+    ap.add_argument("--tq", type=int, default=8, help="queries per streaming pass (8|16|32); 8 keeps the scan HBM-bound")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
+    ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from iscc_search_amd import _lib
+    from iscc_search_amd.engine import HipEngine
+    from iscc_search_amd.sharded import HipShardOps, ShardedTable, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    words = (args.nbytes + 7) // 8
+    engine = HipEngine(local_rank)
+    engine.set_option("queries_per_pass", args.tq)
+    table = engine.open_table(_lib.METRIC_HAMMING, 1, args.nbytes)
+    lo, hi = shard_range(args.rows, rank, world)
+    table.add_synthetic(args.nbytes, hi - lo, SEED_CODES, first_row=lo, key_base=0)
+    sharded = ShardedTable(HipShardOps(table, device))
+
+    q, planted = make_queries(args.queries, args.rows, words)
+
+    def step():
+        return sharded.search(q, None, args.k)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # correctness gate outside the timed region: planted neighbours must come back first
+    keys, ham, pbits, cnt = step()
+    for j, (r, f) in planted.items():
+        assert int(cnt[j]) == min(args.k, args.rows), (j, cnt[j])
+        assert int(ham[j, 0]) <= f, f"planted neighbour of query {j} not found: {ham[j, :3]} vs {f}"
+        if f == 0:
+            assert int(keys[j, 0]) == r or int(ham[j, 0]) == 0
+    assert np.all(np.diff(ham.astype(np.int64), axis=1)[:, : args.k - 1] >= 0), "results not sorted"
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    engine.stats(reset=True)
+    if not args.no_profile:
+        engine.set_option("profile", 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    engine.set_option("profile", 0)
+    st = engine.stats(reset=True)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    total_queries = args.queries * args.steps
+    qps = total_queries / elapsed
+    achieved = (st["scan_bytes"] / 1e9) / (st["scan_ms"] / 1e3) if st["scan_ms"] > 0 else None
+    out = {
+        "metric": "queries/sec, exact Hamming k-NN (achieved HBM GB/s in roofline)",
+        "value": qps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.rows} x {args.nbytes * 8}-bit codes, brute-force Hamming k={args.k}, "
+                        f"{args.queries} queries/step in passes of T_q={args.tq}, rows sharded over {world} GPU(s)",
+            "rows_total": args.rows,
+            "rows_per_gpu": hi - lo,
+            "code_bits": args.nbytes * 8,
+            "k": args.k,
+            "queries_per_step": args.queries,
+            "queries_per_pass": args.tq,
+            "parallelism": f"row-shard x{world}, one all-gather of per-shard top-k",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "scan_kernel<W=%d,COLLECT>" % words,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+            "traffic": None,
+            "launches": st["scan_launches"],
+            "avg_launch_ms": (st["scan_ms"] / st["scan_launches"]) if st["scan_launches"] else None,
+            "algorithmic_bytes_per_launch": (st["scan_bytes"] / st["scan_launches"]) if st["scan_launches"] else None,
+            "measured_copy_ceiling_GBs": 6290.0,
+        },
+        "whole_step_GBs": (st["scan_bytes"] / 1e9) / elapsed,
+        "fallback_queries": st["fallback_queries"],
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, q, words)
+
+    if rank == 0:
+        print(json.dumps(out))
+    table.drop()
+    engine.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, q, words):
+    """The oracle (CPU restatement of the same exact search) on the host cores, bounded to ~10-30 s."""
+    from oracle import oracle_num_threads, oracle_splitmix64_fill, oracle_topk
+
+    rows = args.rows
+    cols = [oracle_splitmix64_fill(rows, SEED_CODES, stride=4, lane=w) for w in range(words)]
+    code_words = np.ascontiguousarray(np.stack(cols, axis=1))
+    if args.nbytes % 8:
+        code_words[:, -1] &= np.uint64((MASK64 << (8 * (8 - args.nbytes % 8))) & MASK64)
+    keys = np.arange(rows, dtype=np.uint64)
+    threads = oracle_num_threads()
+    nq = args.cpu_queries
+    if nq <= 0:
+        # calibrate on 2 queries, then size the sample for ~15 s
+        t0 = time.perf_counter()
+        oracle_topk(0, keys, code_words, None, q[:2], None, args.k, fixed_nbytes=args.nbytes)
+        per_q = (time.perf_counter() - t0) / 2
+        # the oracle splits >= 8 queries across threads: keep every thread busy
+        nq = int(max(threads, min(args.queries, 15.0 * threads / max(per_q * 2, 1e-6)) // threads * threads))
+    t0 = time.perf_counter()
+    oracle_topk(0, keys, code_words, None, q[:nq], None, args.k, fixed_nbytes=args.nbytes)
+    dt = time.perf_counter() - t0
+    return {
+        "value": nq / dt,
+        "unit": "queries/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{nq} of the step's queries over all {rows} rows ({dt:.1f} s of CPU work, {threads} OpenMP threads)",
+        "GBs": nq * rows * 8 * words / dt / 1e9,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -126,12 +126,14 @@ int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const u
  *   d_records[nq*k] (isccsearch_record), d_counts[nq]; queries must share one byte length.
  *   The call returns after the library's stream has drained, so the buffers can go straight
  *   into an RCCL all-gather on any stream.
- * merge_device: k-way merge of n_lists gathered result sets laid out [n_lists][nq][k] /
- *   [n_lists][nq] in DEVICE memory into host outputs shaped as for isccsearch_search. */
+ * merge_device: k-way merge of n_lists result sets held in DEVICE memory into host outputs shaped
+ *   as for isccsearch_search.  List l has its records [nq][k] at d_records + l*list_stride and its
+ *   counts [nq] at d_counts + l*count_stride (strides in bytes), so one all-gathered buffer of
+ *   per-rank blocks {records | counts} can be merged in place. */
 int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                              const uint8_t* q_nbytes, uint32_t k, void* d_records, uint32_t* d_counts);
 int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
-                            const void* d_records, const uint32_t* d_counts,
+                            const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
                             uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
 
 #ifdef __cplusplus

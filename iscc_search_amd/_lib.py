@@ -90,7 +90,7 @@ def load_library():
         "isccsearch_add_synthetic": (i, [vp, u32, i, u64, u64, u64, u64]),
         "isccsearch_search": (i, [vp, u32, u32, u64p, u8p, u32, u64p, u32p, u16p, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
-        "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64p, u32p, u16p, u32p]),
+        "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, u64p, u32p, u16p, u32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -117,7 +117,7 @@ struct isccsearch_handle {
     hipStream_t stream = nullptr;
     std::vector<std::unique_ptr<Table>> tables;
     // options
-    int tq = 16;
+    int tq = 8;   // queries per streaming pass: 8 keeps the scan HBM-bound
     bool profile = false;
     bool nontemporal = true;
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
@@ -455,7 +455,9 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
     }
 
     if (multi) {
-        isk::MergeParams mp{h->d_lists.p, h->d_listcnt.p, d_out, d_out_cnt, (uint32_t)jobs.size(), nq, k};
+        isk::MergeParams mp{reinterpret_cast<const unsigned char*>(h->d_lists.p), reinterpret_cast<const unsigned char*>(h->d_listcnt.p),
+                            (uint64_t)nq * k * sizeof(isk::Record), (uint64_t)nq * sizeof(uint32_t),
+                            d_out, d_out_cnt, (uint32_t)jobs.size(), nq, k};
         hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
     }
     HIPOK(hipGetLastError());
@@ -954,7 +956,7 @@ int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, 
 }
 
 int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
-                            const void* d_records, const uint32_t* d_counts,
+                            const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
                             uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
     if (!h) return fail(-EINVAL, "handle is NULL");
     if (nq == 0) return 0;
@@ -965,7 +967,9 @@ int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq,
     int rc;
     if ((rc = h->d_final.ensure((size_t)nq * k))) return rc;
     if ((rc = h->d_outcnt.ensure(nq))) return rc;
-    isk::MergeParams mp{static_cast<const isk::Record*>(d_records), d_counts, h->d_final.p, h->d_outcnt.p, n_lists, nq, k};
+    if (list_stride % 8 || count_stride % 4 || (uintptr_t)d_records % 8 || (uintptr_t)d_counts % 4) return fail(-EINVAL, "misaligned record/count blocks");
+    isk::MergeParams mp{static_cast<const unsigned char*>(d_records), static_cast<const unsigned char*>(d_counts),
+                        list_stride, count_stride, h->d_final.p, h->d_outcnt.p, n_lists, nq, k};
     hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
     HIPOK(hipGetLastError());
     h->h_final.resize((size_t)nq * k);

@@ -87,6 +87,27 @@ __device__ __forceinline__ u32x4 load16(const uint64_t* p) {
     else return *q;
 }
 
+// Streaming loads of the scan kernel, issued from inline asm so that the PREFETCH stays in flight:
+// hipcc's own s_waitcnt insertion drained it at the loop head (vmcnt(0) in front of the next
+// prefetch's address arithmetic).  The compiler does not count these loads, so every use of a
+// destination goes through wait_tile() first (counted s_waitcnt vmcnt + register ties).
+// saddr form: 64-bit scalar base + 32-bit per-lane byte offset.
+template <bool NT>
+__device__ __forceinline__ void gload16(u32x4& dst, const void* sbase, uint32_t voff) {
+    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding, then tie the tile's
+// registers to the wait so that no use can be scheduled above it
+template <int N, int U, int W>
+__device__ __forceinline__ void wait_tile(u32x4 (&v)[U][W]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int w = 0; w < W; ++w) asm volatile("" : "+v"(v[u][w]));
+}
+
 template <int MODE>
 __device__ __forceinline__ void emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
     if constexpr (MODE == MODE_COLLECT) {
@@ -131,17 +152,17 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
     uint32_t voff[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) voff[u] = tid * 16u + (uint32_t)u * (BLOCK * 16u);
-    for (uint64_t tile = blockIdx.x; tile < n_full; tile += gridDim.x) {
-        const uint64_t base = tile * TILE + (uint64_t)tid * 2;
-        u32x4 v[U][W];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const char* tb = reinterpret_cast<const char*>(p.col[w]) + tile * (uint64_t)(TILE * 8);
-                v[u][w] = load16<NT>(reinterpret_cast<const uint64_t*>(tb + voff[u]));
-            }
 
+    auto load_tile = [&](u32x4 (&v)[U][W], uint64_t tile) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const char* tb = reinterpret_cast<const char*>(p.col[w]) + tile * (uint64_t)(TILE * 8);   // uniform
+#pragma unroll
+            for (int u = 0; u < U; ++u) gload16<NT>(v[u][w], tb, voff[u]);
+        }
+    };
+
+    auto process = [&](const u32x4 (&v)[U][W], uint64_t tile) {
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < TQ; ++q) {
@@ -163,6 +184,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
         }
         if ((int32_t)m >= 0) {
             // rare: at least one (row, query) pair of this lane is within its threshold
+            const uint64_t base = tile * TILE + (uint64_t)tid * 2;
 #pragma unroll 1
             for (int q = 0; q < TQ; ++q) {
                 const uint32_t b = p.bias[q0 + q];
@@ -188,6 +210,34 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                     if ((int32_t)a1 >= 0) emit<MODE>(p, q0 + q, a1 - b, row + 1);
                 }
             }
+        }
+    };
+
+    // software pipeline: the loads of the next tile are in flight while the current one is scored.
+    // The prefetch is UNCONDITIONAL (past the end it re-reads the block's last tile) so that exactly
+    // U*W younger loads are outstanding at every wait: s_waitcnt vmcnt(U*W) retires the current tile
+    // and leaves the prefetch alone.  (The rare emit path may add compiler-counted stores/atomics in
+    // between; more outstanding operations only make the counted wait stricter, never weaker.)
+    {
+        u32x4 va[U][W], vb[U][W];
+        uint64_t tile = blockIdx.x;
+        if (tile < n_full) {
+            const uint64_t last = n_full - 1;
+            load_tile(va, tile);
+            for (;;) {
+                const uint64_t t1 = tile + gridDim.x;
+                load_tile(vb, t1 < n_full ? t1 : last);
+                wait_tile<U * W>(va);
+                process(va, tile);
+                if (t1 >= n_full) break;
+                const uint64_t t2 = t1 + gridDim.x;
+                load_tile(va, t2 < n_full ? t2 : last);
+                wait_tile<U * W>(vb);
+                process(vb, t1);
+                if (t2 >= n_full) break;
+                tile = t2;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) prefetch
         }
     }
 
@@ -526,10 +576,12 @@ __global__ __launch_bounds__(BLOCK) void fullhist_kernel(const FullHistParams p)
 //   list that sort before it (binary search); ranks are distinct because keys are.
 // ---------------------------------------------------------------------------------------------
 struct MergeParams {
-    const Record* lists;      // [n_lists][nq][k]
-    const uint32_t* counts;   // [n_lists][nq]
-    Record* out;              // [nq][k]
-    uint32_t* out_count;      // [nq]
+    const unsigned char* lists;   // list l: records at lists + l*list_stride, laid out [nq][k]
+    const unsigned char* counts;  // list l: counts  at counts + l*count_stride, laid out [nq]
+    uint64_t list_stride;         // bytes between the record blocks of consecutive lists
+    uint64_t count_stride;        // bytes between the count blocks of consecutive lists
+    Record* out;                  // [nq][k]
+    uint32_t* out_count;          // [nq]
     uint32_t n_lists, nq, k;
 };
 __device__ __forceinline__ bool rec_less(const Record& a, const Record& b) {
@@ -539,19 +591,23 @@ __device__ __forceinline__ bool rec_less(const Record& a, const Record& b) {
 }
 __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams p) {
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    auto list_of = [&](uint32_t l) { return reinterpret_cast<const Record*>(p.lists + (uint64_t)l * p.list_stride) + (uint64_t)q * p.k; };
+    auto count_of = [&](uint32_t l) {
+        const uint32_t c = reinterpret_cast<const uint32_t*>(p.counts + (uint64_t)l * p.count_stride)[q];
+        return c < p.k ? c : p.k;
+    };
     uint32_t total = 0;
-    for (uint32_t l = 0; l < p.n_lists; ++l) total += p.counts[(uint64_t)l * p.nq + q];
+    for (uint32_t l = 0; l < p.n_lists; ++l) total += count_of(l);
     const uint32_t keff = total < p.k ? total : p.k;
     for (uint32_t e = tid; e < p.n_lists * p.k; e += BLOCK) {
         const uint32_t l = e / p.k, i = e % p.k;
-        const uint32_t cl = p.counts[(uint64_t)l * p.nq + q];
-        if (i >= cl) continue;
-        const Record me = p.lists[((uint64_t)l * p.nq + q) * p.k + i];
+        if (i >= count_of(l)) continue;
+        const Record me = list_of(l)[i];
         uint32_t rank = i;
         for (uint32_t o = 0; o < p.n_lists && rank < keff; ++o) {
             if (o == l) continue;
-            const Record* lst = p.lists + ((uint64_t)o * p.nq + q) * p.k;
-            uint32_t lo = 0, hi = p.counts[(uint64_t)o * p.nq + q];
+            const Record* lst = list_of(o);
+            uint32_t lo = 0, hi = count_of(o);
             // elements of list o sorting before `me`; an (impossible) exact tie goes to the lower list id
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;

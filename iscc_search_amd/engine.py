@@ -86,13 +86,14 @@ class HipEngine:
         _lib.check(self._lib.isccsearch_stats_get(self.handle, ctypes.byref(st), 1 if reset else 0))
         return st.as_dict()
 
-    def merge_device(self, n_lists, nq, k, key_words, d_records_ptr, d_counts_ptr):
-        # type: (int, int, int, int, int, int) -> tuple
-        """k-way merge of gathered per-shard results held in device memory (``isccsearch_merge_device``)."""
+    def merge_device(self, n_lists, nq, k, key_words, d_records_ptr, d_counts_ptr, list_stride, count_stride):
+        # type: (int, int, int, int, int, int, int, int) -> tuple
+        """k-way merge of per-shard result blocks held in device memory (``isccsearch_merge_device``)."""
         out = _alloc_out(nq, k, key_words)
         _lib.check(
             self._lib.isccsearch_merge_device(
                 self.handle, n_lists, nq, k, key_words, ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr),
+                list_stride, count_stride,
                 _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32),
                 _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32),
             )

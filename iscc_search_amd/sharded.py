@@ -1,0 +1,100 @@
+"""
+Row-range sharding of one table across the GPUs of a node (one process per GPU).
+
+The reference has no distributed path at all (single process, ``usearch/manager.py:43-46``); this is
+the MI355X-native addition SURVEY.md section 8e describes.  Rows are independent and top-k is a
+decomposable reduction, so the only exchange is ONE all-gather of the per-shard results
+(one block of ``nq * k`` 24-byte records + ``nq`` counts per rank; RCCL over xGMI when the process group's backend
+is ``nccl``), followed by a k-way merge on every rank (``merge_kernel``).  No ring all-reduce, no
+second collective: at 160 KB per rank for 1 024 queries the exchange is latency bound.
+
+``ShardedTable`` is transport- and engine-agnostic: it drives a small "ops" object.
+``HipShardOps`` is the product implementation (device buffers owned by torch, kernels by the
+C-ABI); tests drive the same class over gloo with an oracle-backed ops object.
+"""
+
+import numpy as np
+
+RECORD_BYTES = 24
+
+
+def shard_range(n_rows, rank, world_size):
+    # type: (int, int, int) -> tuple[int, int]
+    """Contiguous row range [lo, hi) of ``rank``: sizes differ by at most one row."""
+    lo = n_rows * rank // world_size
+    hi = n_rows * (rank + 1) // world_size
+    return lo, hi
+
+
+def shard_of_key(key_lo, world_size):
+    # type: (int, int) -> int
+    """Owner rank of a key for hash-routed (mutable) tables."""
+    x = (int(key_lo) * 0x9E3779B97F4A7C15) & (2**64 - 1)
+    return (x >> 32) % world_size
+
+
+def block_bytes(nq, k):
+    # type: (int, int) -> tuple[int, int]
+    """Per-rank exchange block {records [nq][k] | counts [nq] | pad}: (record bytes, block bytes)."""
+    rec = nq * k * RECORD_BYTES
+    return rec, rec + (nq * 4 + 7) // 8 * 8
+
+
+class HipShardOps:
+    """Local search + merge on one GPU through the C-ABI; buffers are torch tensors on that GPU."""
+
+    def __init__(self, table, device):
+        import torch
+
+        self.torch = torch
+        self.table = table
+        self.engine = table.engine
+        self.device = torch.device(device)
+        self.key_words = table.key_words
+
+    def local_search(self, q_words, q_nbytes, k):
+        """One device block {records | counts} holding this shard's exact top-k."""
+        torch = self.torch
+        nq = q_words.shape[0]
+        rec_bytes, blk = block_bytes(nq, k)
+        buf = torch.empty(blk, dtype=torch.uint8, device=self.device)
+        # the library drains its own stream before returning, so the block can go straight into
+        # the collective on torch's stream
+        self.table.search_device(q_words, q_nbytes, k, buf.data_ptr(), buf.data_ptr() + rec_bytes)
+        return buf
+
+    def merge(self, gathered, n_lists, nq, k):
+        rec_bytes, blk = block_bytes(nq, k)
+        self.torch.cuda.synchronize(self.device)   # the all-gather ran on torch's / RCCL's stream
+        base = gathered.data_ptr()
+        return self.engine.merge_device(n_lists, nq, k, self.key_words, base, base + rec_bytes, blk, blk)
+
+
+class ShardedTable:
+    """
+    One logical table whose rows are spread over the ranks of a ``torch.distributed`` process group.
+
+    Every rank calls ``search`` with the SAME queries and gets the SAME global top-k back.
+    """
+
+    def __init__(self, ops, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.ops = ops
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def search(self, q_words, q_nbytes, k):
+        # type: (np.ndarray, np.ndarray | None, int) -> tuple
+        nq = q_words.shape[0]
+        block = self.ops.local_search(q_words, q_nbytes, k)
+        if self.world_size == 1:
+            return self.ops.merge(block, 1, nq, k)
+        import torch
+
+        gathered = torch.empty(self.world_size * block.numel(), dtype=block.dtype, device=block.device)
+        # the one exchange step of the path: [world] x {records [nq][k] | counts [nq]}
+        self.dist.all_gather_into_tensor(gathered, block, group=self.group)
+        return self.ops.merge(gathered, self.world_size, nq, k)

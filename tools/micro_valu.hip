@@ -1,0 +1,62 @@
+// micro_valu.hip -- issue-rate microbenchmark for the VALU ops of the scan kernel (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 -o micro_valu micro_valu.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t s0, uint32_t s1) {
+    uint32_t a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = threadIdx.x * 2654435761u + j * 40503u + blockIdx.x;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (OP == 0) { asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[j]) : "s"(s0)); }
+                if (OP == 1) { asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a[j]) : "s"(s1)); }
+                if (OP == 2) { asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(a[(j + 1) & 7])); }
+                if (OP == 3) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[j]) : "s"(s1)); }
+                if (OP == 4) { asm volatile("v_xor_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %0, %2" : "+v"(a[j]) : "s"(s0), "s"(s1)); }
+            }
+        }
+    }
+    uint32_t t = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += a[j];
+    out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
+template <int OP>
+void run(const char* name, int ops_per_inner, int blocks_per_cu) {
+    int cus = 256;
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0); cus = p.multiProcessorCount;
+    int blocks = cus * blocks_per_cu;
+    uint32_t* out; hipMalloc(&out, blocks * 256 * 4);
+    int iters = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<OP><<<blocks, 256>>>(out, 10, 0x12345678u, 7u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<OP><<<blocks, 256>>>(out, iters, 0x12345678u, 7u);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double wave_instr = (double)blocks * 4 * iters * 64.0 * ops_per_inner;   // per wave: iters*8*8 inner
+    double per_simd = wave_instr / (cus * 4.0);
+    double cyc = ms * 1e-3 * 2.4e9;
+    printf("%-10s blocks/CU=%d  %.3f ms  %.2f cycles(@2.4GHz) per wave-instr per SIMD  (%.1f T lane-ops/s)\n",
+           name, blocks_per_cu, ms, cyc / per_simd, wave_instr * 64 / (ms * 1e-3) / 1e12);
+    hipFree(out);
+}
+
+int main() {
+    for (int b : {1, 2, 4, 8}) {
+        run<0>("v_xor", 1, b);
+        run<1>("v_bcnt", 1, b);
+        run<2>("v_min3", 1, b);
+        run<3>("v_add", 1, b);
+        run<4>("xor+bcnt", 2, b);
+    }
+    return 0;
+}
