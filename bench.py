@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     args = ap.parse_args()
 
     import torch
@@ -102,6 +103,9 @@ def main():
     words = (args.nbytes + 7) // 8
     engine = HipEngine(local_rank)
     engine.set_option("queries_per_pass", args.tq)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        engine.set_option(name, int(val))
     table = engine.open_table(_lib.METRIC_HAMMING, 1, args.nbytes)
     lo, hi = shard_range(args.rows, rank, world)
     table.add_synthetic(args.nbytes, hi - lo, SEED_CODES, first_row=lo, key_base=0)

@@ -120,6 +120,8 @@ struct isccsearch_handle {
     int tq = 8;   // queries per streaming pass: 8 keeps the scan HBM-bound
     bool profile = false;
     bool nontemporal = true;
+    uint64_t boot_rows = 16384;    // rows of the threshold bootstrap (exact histogram per query)
+    uint64_t sample_div = 1024;    // sample ~ n*k/sample_div rows -> ~sample_div candidates per query
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
     // scratch
@@ -255,9 +257,14 @@ void launch_scan(int W, bool mask, int tq, int mode, bool nt, dim3 grid, hipStre
 }
 int tile_rows_for(int W) { return W == 1 ? isk::tile_rows<1>() : W == 2 ? isk::tile_rows<2>() : W == 3 ? isk::tile_rows<3>() : isk::tile_rows<4>(); }
 
-uint32_t scan_grid_x(H* h, int W, uint64_t rows) {
+// blocks per query group.  Full-table scans give every group the whole chip (groups run one after
+// the other, each streaming the table once).  Sample scans cover few tiles: spread the chip's
+// resident blocks over ALL groups so that each block walks several tiles and the per-block
+// prologue (queries -> SGPRs) and the load pipeline are amortised.
+uint32_t scan_grid_x(H* h, int W, uint64_t rows, uint32_t groups = 1, bool sample = false) {
     const uint64_t tiles = rows / (uint64_t)tile_rows_for(W);
-    const uint64_t maxb = (uint64_t)h->cus * 8;
+    uint64_t maxb = (uint64_t)h->cus * 8;
+    if (sample) maxb = std::max<uint64_t>(8, maxb / std::max<uint32_t>(1, groups));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, maxb));
 }
 
@@ -355,7 +362,7 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         uint32_t* out_cnt = multi ? h->d_listcnt.p + ji * (size_t)nq : d_out_cnt;
 
         // 1. bootstrap threshold from the first s0 rows
-        const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(4096, std::min<uint64_t>(65536, 64ull * k)));
+        const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
         isk::BootParams bp{};
         for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
         bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
@@ -368,12 +375,12 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         sp.mask_lo = (uint32_t)j.mask_last; sp.mask_hi = (uint32_t)(j.mask_last >> 32);
 
         // 2. sample scan: tighten the threshold to the k-th smallest of the first `sample` rows
-        const uint64_t want = (s.n / 1024 + 1) * (uint64_t)k;      // ~ n*k/1024 rows -> ~1024 candidates per query
+        const uint64_t want = (s.n / h->sample_div + 1) * (uint64_t)k;   // ~ n*k/sample_div rows -> ~sample_div candidates per query
         const uint64_t sample = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, want));
         if (sample > s0) {
             HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
             sp.n_rows = sample;
-            launch_scan((int)j.W, j.mask, tq, isk::MODE_HIST, h->nontemporal, dim3(scan_grid_x(h, j.W, sample), groups), h->stream, sp);
+            launch_scan((int)j.W, j.mask, tq, isk::MODE_HIST, h->nontemporal, dim3(scan_grid_x(h, j.W, sample, groups, true), groups), h->stream, sp);
             isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, sample)};
             hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
             h->stats.sample_bytes += sample * 8 * j.W * groups;
@@ -571,6 +578,8 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "profile")) { h->profile = value != 0; return 0; }
     if (!strcmp(name, "nontemporal")) { h->nontemporal = value != 0; return 0; }
+    if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
+    if (!strcmp(name, "sample_div")) { if (value < 64 || value > 8192) return fail(-EINVAL, "sample_div must be 64..8192"); h->sample_div = (uint64_t)value; return 0; }
     return fail(-EINVAL, "unknown option '%s'", name);
 }
 

@@ -1,0 +1,479 @@
+"""
+``hip:///`` backend: ``HipIndexManager`` implements the reference's ``IsccIndexProtocol``
+(``iscc_search/protocols/index.py:19-174``) over the HIP engine.
+
+Layout mirrors the reference's usearch backend (``iscc_search/indexes/usearch/``):
+  ``HipIndexManager``  ~ ``UsearchIndexManager`` (``manager.py:25-335``): named indexes, protocol methods
+  ``HipIndex``         ~ ``UsearchIndex`` (``index.py:87-2045``): one index = asset store + one NPHD
+                         table per unit type + one simprint table per simprint type
+What differs by design: there is no LMDB and no HNSW file -- assets live in a host dict (as in the
+reference's ``memory://`` backend, ``memory/index.py``), codes live in HBM, and every similarity
+search is the exact GPU scan.  Scoring, thresholds, aggregation, self-exclusion, ordering and error
+messages follow ``index.py:735-881`` and ``:1357-1469``.
+"""
+
+import re
+import threading
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+from urllib.parse import parse_qs, urlparse
+
+import numpy as np
+
+from iscc_search_amd import codec
+from iscc_search_amd._lib import MAX_K
+from iscc_search_amd.nphd import HipNphdIndex
+from iscc_search_amd.schema import (
+    IsccAddResult, IsccChunkMatch, IsccEntry, IsccGlobalMatch, IsccIndex, IsccMatchedChunk, IsccQuery,
+    IsccSearchResult, Status, Types,
+)
+from iscc_search_amd.simprint import HipSimprintIndex, pack_chunk_pointer
+
+INDEX_NAME_RE = re.compile(r"^[a-z][a-z0-9]*$")
+
+
+@dataclass
+class HipOptions:
+    """Knobs with the reference's names and defaults (``iscc_search/options.py:139-164, :95-100``)."""
+
+    match_threshold_units: float = 0.75
+    match_threshold_simprints: float = 0.75
+    confidence_exponent: int = 4
+    oversampling_factor: int = 20
+    max_dim: int = 256
+
+
+def validate_index_name(name):
+    # type: (str) -> None
+    if not isinstance(name, str) or not INDEX_NAME_RE.match(name) or len(name) > 32:
+        raise ValueError(
+            f"Invalid index name: '{name}'. Must match pattern ^[a-z][a-z0-9]*$ "
+            f"(start with lowercase letter, followed by lowercase letters/digits only)"
+        )
+
+
+def normalize_query(query):
+    # type: (IsccQuery) -> IsccQuery
+    """Bidirectional units <-> iscc_code normalisation (``iscc_search/indexes/common.py:275-330``)."""
+    if query.units and query.iscc_code:
+        return query
+    if query.units and not query.iscc_code:
+        try:
+            return query.model_copy(update={"iscc_code": codec.gen_iscc_code(list(query.units), wide=True)})
+        except ValueError:
+            return query
+    if query.iscc_code and not query.units:
+        return query.model_copy(update={"units": [str(u) for u in codec.code_units(query.iscc_code)]})
+    if query.simprints:
+        return query
+    raise ValueError("Query must have 'iscc_code', 'units', or 'simprints' for search")
+
+
+def _sp_string(s):
+    return s.root if hasattr(s, "root") else s
+
+
+class HipIndex:
+    """One named index: host asset store + device tables."""
+
+    def __init__(self, engine, options=None):
+        # type: (object, HipOptions | None) -> None
+        self._engine = engine
+        self._opts = options or HipOptions()
+        self._lock = threading.RLock()
+        self._realm_id = None  # type: Optional[int]
+        self._assets = {}  # type: Dict[int, IsccEntry]          key -> entry (without simprints)
+        self._asset_units = {}  # type: Dict[int, Dict[str, bytes]]  key -> {unit_type: body} as indexed
+        self._unit_tables = {}  # type: Dict[str, HipNphdIndex]
+        self._sp_tables = {}  # type: Dict[str, HipSimprintIndex]
+        self._sp_assets = {}  # type: Dict[str, Dict[bytes, list]]   sp_type -> body -> [(sp_bytes, chunk_ptr)]
+        self._sp_freq = {}  # type: Dict[str, Dict[bytes, Dict[bytes, int]]]  sp_type -> sp_bytes -> {body: n}
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def __len__(self):
+        return len(self._assets)
+
+    def _unit_table(self, unit_type):
+        t = self._unit_tables.get(unit_type)
+        if t is None:
+            t = self._unit_tables[unit_type] = HipNphdIndex(self._engine, max_dim=self._opts.max_dim)
+        return t
+
+    def _sp_table(self, sp_type, ndim):
+        t = self._sp_tables.get(sp_type)
+        if t is None:
+            t = self._sp_tables[sp_type] = HipSimprintIndex(self._engine, ndim=ndim, oversampling_factor=self._opts.oversampling_factor)
+            self._sp_assets[sp_type] = {}
+            self._sp_freq[sp_type] = {}
+        return t
+
+    @staticmethod
+    def _fingerprint(sp_list):
+        return tuple(sorted((codec.decode_base64(sp.simprint), sp.offset, sp.size) for sp in sp_list))
+
+    def _doc_freq(self, sp_type, sp_bytes):
+        # distinct assets carrying exactly this simprint (``lmdb_ops.count_doc_freq``, :139-166)
+        return len(self._sp_freq.get(sp_type, {}).get(sp_bytes, ()))
+
+    # -- add ---------------------------------------------------------------------------------------
+    def add_assets(self, assets):
+        # type: (List[IsccEntry]) -> List[IsccAddResult]
+        """Semantics of ``usearch/index.py:194-537`` (status, batch dedup keep-last, remove-before-add)."""
+        if not assets:
+            return []
+        with self._lock:
+            if self._realm_id is None:
+                if assets[0].iscc_id is None:
+                    raise ValueError("Asset must have iscc_id field when adding to index")
+                self._realm_id = codec.validate_iscc_id(assets[0].iscc_id).stype
+            results = []
+            unit_batches = {}  # type: Dict[str, Dict[int, bytes]]
+            updated_keys = set()
+            sp_batches = {}  # type: Dict[str, tuple]
+            sp_deleted = {}  # type: Dict[str, list]
+            last_occurrence = {a.iscc_id: i for i, a in enumerate(assets)}
+            batch_seen = set()
+            staged = []
+            for i, asset in enumerate(assets):
+                if asset.iscc_id is None:
+                    raise ValueError("Asset must have iscc_id field when adding to index")
+                id_obj = codec.validate_iscc_id(asset.iscc_id)
+                if id_obj.stype != self._realm_id:
+                    raise ValueError(
+                        f"Realm ID mismatch: index has realm={self._realm_id}, but asset '{asset.iscc_id}' "
+                        f"has realm={id_obj.stype}. All assets in an index must have the same realm ID."
+                    )
+                key = int.from_bytes(id_obj.body, "big")
+                existing = self._assets.get(key)
+                status = Status.updated if (existing is not None or key in batch_seen) else Status.created
+                batch_seen.add(key)
+                results.append(IsccAddResult(iscc_id=asset.iscc_id, status=status))
+                if i != last_occurrence[asset.iscc_id]:
+                    continue
+                stored = asset.model_copy(update={"simprints": None})
+                fingerprints = {t: self._fingerprint(lst) for t, lst in (asset.simprints or {}).items()}
+                # idempotent re-add: nothing to do when entry and simprints are already indexed identically
+                if existing is not None and existing == stored and all(
+                    self._fingerprint_of(t, id_obj.body) == fp for t, fp in fingerprints.items()
+                ):
+                    continue
+                if existing is not None:
+                    updated_keys.add(key)
+                # validate / decode units before touching any state
+                unit_map = {}
+                for unit_str in asset.units or []:
+                    unit = codec.Iscc(unit_str)
+                    unit_map[unit.unit_type] = unit.body   # same type at two lengths: last one wins (:423-430)
+                sp_decoded = {}
+                for sp_type, sp_list in (asset.simprints or {}).items():
+                    sp_decoded[sp_type] = [(codec.decode_base64(sp.simprint), pack_chunk_pointer(id_obj.body, sp.offset, sp.size)) for sp in sp_list]
+                staged.append((key, id_obj.body, stored, unit_map, sp_decoded))
+
+            for key, body, stored, unit_map, sp_decoded in staged:
+                self._assets[key] = stored
+                for unit_type, ubody in unit_map.items():
+                    unit_batches.setdefault(unit_type, {})[key] = ubody
+                self._asset_units[key] = unit_map
+                for sp_type, pairs in sp_decoded.items():
+                    self._sp_table(sp_type, len(pairs[0][0]) * 8)
+                    old = self._sp_assets[sp_type].pop(body, None)
+                    if old is not None:
+                        sp_deleted.setdefault(sp_type, []).extend(ptr for _, ptr in old)
+                        for sp_bytes, _ in old:
+                            owners = self._sp_freq[sp_type].get(sp_bytes)
+                            if owners is not None:
+                                owners[body] = owners.get(body, 1) - 1
+                                if owners[body] <= 0:
+                                    del owners[body]
+                                if not owners:
+                                    del self._sp_freq[sp_type][sp_bytes]
+                    self._sp_assets[sp_type][body] = pairs
+                    keys_b, vecs_b = sp_batches.setdefault(sp_type, ([], []))
+                    for sp_bytes, ptr in pairs:
+                        owners = self._sp_freq[sp_type].setdefault(sp_bytes, {})
+                        owners[body] = owners.get(body, 0) + 1
+                        keys_b.append(ptr)
+                        vecs_b.append(np.frombuffer(sp_bytes, dtype=np.uint8))
+
+            # device side: remove-before-add for updated assets, then one batched add per table
+            for unit_type, items in unit_batches.items():
+                table = self._unit_table(unit_type)
+                to_remove = [k for k in items if k in updated_keys]
+                if to_remove:
+                    table.remove(to_remove)
+                table.add(list(items.keys()), list(items.values()))
+            for sp_type, (ckeys, vecs) in sp_batches.items():
+                table = self._sp_tables[sp_type]
+                if sp_type in sp_deleted:
+                    table.remove(sp_deleted[sp_type])
+                table.add_raw(ckeys, vecs)
+            return results
+
+    def _fingerprint_of(self, sp_type, body):
+        pairs = self._sp_assets.get(sp_type, {}).get(body)
+        if pairs is None:
+            return None
+        from iscc_search_amd.simprint import unpack_chunk_pointer
+
+        return tuple(sorted((sp, *unpack_chunk_pointer(ptr)[1:]) for sp, ptr in pairs))
+
+    # -- get ---------------------------------------------------------------------------------------
+    def get_asset(self, iscc_id):
+        # type: (str) -> IsccEntry
+        if self._realm_id is not None:
+            codec.validate_iscc_id(iscc_id, expected_realm=self._realm_id)
+        key = codec.iscc_id_to_int(iscc_id)
+        with self._lock:
+            asset = self._assets.get(key)
+        if asset is None:
+            raise FileNotFoundError(f"Asset '{iscc_id}' not found in index")
+        return asset
+
+    # -- search ------------------------------------------------------------------------------------
+    def _search_similarity_unit(self, unit_type, body, limit):
+        # type: (str, bytes, int) -> Dict[int, float]
+        """``usearch/index.py:2024-2045``: score = max(0, 1 - NPHD)."""
+        matches = self._unit_tables[unit_type].search(np.frombuffer(body, dtype=np.uint8), count=min(limit, MAX_K))
+        out = {}
+        for key, distance in zip(matches.keys, matches.distances):
+            out[int(key)] = max(0.0, 1.0 - float(distance))
+        return out
+
+    def _search_instance_unit(self, unit_type, body):
+        # type: (str, bytes) -> Dict[int, float]
+        """
+        Bidirectional prefix match of identity codes, every hit scoring 1.0 (``usearch/index.py:1957-2022``).
+        A stored code is a hit iff it agrees with the query on their common prefix, i.e. NPHD == 0:
+        the same GPU scan answers it.  Capped at MAX_K hits per query.
+        """
+        table = self._unit_tables.get(unit_type)
+        if table is None:
+            return {}
+        k = 64
+        while True:
+            m = table.search(np.frombuffer(body, dtype=np.uint8), count=k)
+            zero = [int(key) for key, h in zip(m.keys, m.hamming) if h == 0]
+            if len(zero) < len(m) or len(m) < k or k >= MAX_K:
+                return {key: 1.0 for key in zero}
+            k = min(MAX_K, k * 8)
+
+    def search_assets(self, query, limit=100):
+        # type: (IsccQuery, int) -> IsccSearchResult
+        query_iscc_id = None
+        if query.iscc_id:
+            query_iscc_id = query.iscc_id
+            asset = self.get_asset(query.iscc_id)
+            query = IsccQuery(iscc_code=asset.iscc_code, units=asset.units, simprints=None)
+        query = normalize_query(query)
+        with self._lock:
+            chunk_matches = []
+            if self._sp_tables and query.simprints:
+                chunk_matches = self._search_simprints(query, limit)
+            matches = []
+            if query.units:
+                aggregated = {}  # type: Dict[int, Dict[str, float]]
+                for unit_str in query.units:
+                    unit = codec.Iscc(unit_str)
+                    unit_type = unit.unit_type
+                    if unit_type.startswith("INSTANCE_"):
+                        for key, score in self._search_instance_unit(unit_type, unit.body).items():
+                            aggregated.setdefault(key, {})[unit_type] = score
+                    elif unit_type in self._unit_tables:
+                        for key, score in self._search_similarity_unit(unit_type, unit.body, limit).items():
+                            slot = aggregated.setdefault(key, {})
+                            slot[unit_type] = max(slot.get(unit_type, 0.0), score)
+                scored = []
+                thr, exp = self._opts.match_threshold_units, self._opts.confidence_exponent
+                for key, unit_scores in aggregated.items():
+                    confident = {t: s for t, s in unit_scores.items() if s >= thr}
+                    if not confident:
+                        continue
+                    weight_sum = sum(confident.values())
+                    total = sum(s**exp for s in confident.values()) / weight_sum if weight_sum > 0 else 0.0
+                    scored.append((key, total, unit_scores))
+                if query_iscc_id:
+                    qkey = codec.iscc_id_to_int(query_iscc_id)
+                    scored = [r for r in scored if r[0] != qkey]
+                scored.sort(key=lambda r: r[1], reverse=True)   # stable, as the reference (:836)
+                for key, total, unit_scores in scored[:limit]:
+                    asset = self._assets.get(key)
+                    source = metadata = None
+                    if asset is not None and asset.metadata:
+                        source = asset.metadata.get("source")
+                        metadata = asset.metadata
+                    matches.append(IsccGlobalMatch(
+                        iscc_id=codec.iscc_id_from_int(key, self._realm_id or 0), score=min(1.0, total),
+                        types=unit_scores, source=source, metadata=metadata,
+                    ))
+        if query_iscc_id:
+            chunk_matches = [m for m in chunk_matches if m.iscc_id != query_iscc_id]
+        return IsccSearchResult(query=query, global_matches=matches, chunk_matches=chunk_matches)
+
+    def _search_simprints(self, query, limit):
+        # type: (IsccQuery, int) -> List[IsccChunkMatch]
+        """Per-type search, mean over types, order (-score, iscc_id) (``usearch/index.py:1357-1469``)."""
+        total_assets = len(self._assets)
+        per_asset = {}  # type: Dict[bytes, Dict[str, object]]
+        for sp_type, simprint_objs in query.simprints.items():
+            table = self._sp_tables.get(sp_type)
+            if table is None:
+                continue
+            q_bytes = [codec.decode_base64(_sp_string(s)) for s in simprint_objs]
+            raw = table.search_raw(
+                simprints=q_bytes, limit=limit * 2, threshold=self._opts.match_threshold_simprints, detailed=True,
+                doc_freq_fn=lambda sp, _t=sp_type: self._doc_freq(_t, sp), total_assets=total_assets,
+            )
+            for r in raw:
+                per_asset.setdefault(r.iscc_id_body, {})[sp_type] = r
+        if not per_asset:
+            return []
+        ranked = []
+        for body, type_results in per_asset.items():
+            score = sum(r.score for r in type_results.values()) / len(type_results)
+            digest = codec.decode_base32(codec.iscc_id_from_int(int.from_bytes(body, "big"), self._realm_id or 0)[5:])
+            ranked.append((score, digest, body, type_results))
+        ranked.sort(key=lambda x: (-x[0], x[1]))
+        out = []
+        for score, digest, body, type_results in ranked[:limit]:
+            asset = self._assets.get(int.from_bytes(body, "big"))
+            source = metadata = None
+            if asset is not None and asset.metadata:
+                source = asset.metadata.get("source")
+                metadata = asset.metadata
+            types = {}
+            for sp_type, r in type_results.items():
+                chunks = None
+                if r.chunks is not None:
+                    chunks = [
+                        IsccMatchedChunk(query=codec.encode_base64(c.query), match=codec.encode_base64(c.match),
+                                         score=c.score, freq=max(1, c.freq), offset=c.offset, size=c.size, content=None)
+                        for c in r.chunks
+                    ]
+                types[sp_type] = Types(score=r.score, matches=r.matches, queried=r.queried, chunks=chunks)
+            out.append(IsccChunkMatch(iscc_id="ISCC:" + codec.encode_base32(digest), score=score, types=types, source=source, metadata=metadata))
+        return out
+
+    def close(self):
+        # type: () -> None
+        with self._lock:
+            for t in list(self._unit_tables.values()):
+                t.close()
+            for t in list(self._sp_tables.values()):
+                t.close()
+            self._unit_tables.clear()
+            self._sp_tables.clear()
+
+
+class HipIndexManager:
+    """
+    Protocol-conformant manager of named ``hip:///`` indexes on one GPU.
+
+    The engine (library load, GPU context, stream) is created lazily on first use and released by
+    ``close()``, which is idempotent (``protocols/index.py:162-172``).  Thread-safe: FastAPI calls
+    the sync protocol methods from a thread pool (``docs/explanation/architecture.md:120-126``).
+    """
+
+    def __init__(self, uri="hip:///", engine=None, options=None):
+        # type: (str, object | None, HipOptions | None) -> None
+        parsed = urlparse(uri)
+        if parsed.scheme != "hip":
+            raise ValueError(f"HipIndexManager requires a hip:// URI, got '{uri}'")
+        qs = parse_qs(parsed.query)
+        self.device_id = int(qs.get("device", ["0"])[0])
+        self._engine = engine
+        self._owns_engine = engine is None
+        self._opts = options or HipOptions()
+        self._indexes = {}  # type: Dict[str, HipIndex]
+        self._lock = threading.RLock()
+        self._closed = False
+
+    def _get_engine(self):
+        if self._engine is None:
+            from iscc_search_amd.engine import HipEngine   # raises loudly without library / GPU
+
+            self._engine = HipEngine(self.device_id)
+        return self._engine
+
+    def _index(self, name):
+        # type: (str) -> HipIndex
+        idx = self._indexes.get(name)
+        if idx is None:
+            raise FileNotFoundError(f"Index '{name}' not found")
+        return idx
+
+    # -- protocol ----------------------------------------------------------------------------------
+    def list_indexes(self):
+        # type: () -> List[IsccIndex]
+        with self._lock:
+            return [IsccIndex(name=n, assets=len(i), size=0) for n, i in self._indexes.items()]
+
+    def create_index(self, index):
+        # type: (IsccIndex) -> IsccIndex
+        validate_index_name(index.name)
+        with self._lock:
+            if index.name in self._indexes:
+                raise FileExistsError(f"Index '{index.name}' already exists")
+            self._indexes[index.name] = HipIndex(self._get_engine(), self._opts)
+        return IsccIndex(name=index.name, assets=0, size=0)
+
+    def get_index(self, name):
+        # type: (str) -> IsccIndex
+        with self._lock:
+            return IsccIndex(name=name, assets=len(self._index(name)), size=0)
+
+    def delete_index(self, name):
+        # type: (str) -> None
+        with self._lock:
+            self._index(name).close()
+            del self._indexes[name]
+
+    def add_assets(self, index_name, assets):
+        # type: (str, List[IsccEntry]) -> List[IsccAddResult]
+        with self._lock:
+            idx = self._index(index_name)
+        return idx.add_assets(assets)
+
+    def get_asset(self, index_name, iscc_id):
+        # type: (str, str) -> IsccEntry
+        with self._lock:
+            idx = self._index(index_name)
+        try:
+            return idx.get_asset(iscc_id)
+        except FileNotFoundError:
+            raise FileNotFoundError(f"Asset '{iscc_id}' not found in index '{index_name}'")
+
+    def search_assets(self, index_name, query, limit=100):
+        # type: (str, IsccQuery, int) -> IsccSearchResult
+        with self._lock:
+            idx = self._index(index_name)
+        try:
+            return idx.search_assets(query, limit)
+        except FileNotFoundError:
+            raise FileNotFoundError(f"Asset '{query.iscc_id}' not found in index '{index_name}'")
+
+    def close(self):
+        # type: () -> None
+        with self._lock:
+            if self._closed:
+                return
+            self._closed = True
+            for idx in self._indexes.values():
+                idx.close()
+            self._indexes.clear()
+            if self._owns_engine and self._engine is not None:
+                self._engine.close()
+                self._engine = None
+
+
+def get_index(uri="hip:///", **kwargs):
+    # type: (str, object) -> HipIndexManager
+    """
+    Factory for the ``hip`` scheme, the branch a maintainer adds to the reference's
+    ``options.get_index()`` next to ``iscc_search/options.py:360-371``.
+    """
+    parsed = urlparse(uri)
+    if not parsed.scheme:
+        raise ValueError(f"index URI requires an explicit scheme, got '{uri}'")
+    if parsed.scheme != "hip":
+        raise ValueError(f"Unsupported index URI scheme: '{parsed.scheme}' (this package serves hip://)")
+    return HipIndexManager(uri, **kwargs)

@@ -1,0 +1,133 @@
+"""
+Oracle-backed stand-in for ``HipEngine`` / ``HipTable`` (TEST INFRASTRUCTURE).
+
+Lets the host logic (``nphd.py``, ``simprint.py``, ``index.py``, ``sharded.py``) run in the CPU test
+tier with the CPU oracle answering the searches.  Lives under ``tests/`` because only tests may
+route through ``oracle/``; the product path has no such engine.
+"""
+
+import numpy as np
+
+from oracle import oracle_topk
+
+RECORD_DTYPE = np.dtype(
+    [("key_hi", "<u8"), ("key_lo", "<u8"), ("dist_rank", "<u4"), ("hamming", "<u2"), ("prefix_bits", "<u2")]
+)
+
+
+def rank_table():
+    """Order-preserving rank of h/(8p) over all p in 1..32 bytes (independent of the C++ table)."""
+    from fractions import Fraction
+
+    vals = sorted({Fraction(h, 8 * p) for p in range(1, 33) for h in range(8 * p + 1)})
+    pos = {v: i for i, v in enumerate(vals)}
+    return {(p, h): pos[Fraction(h, 8 * p)] for p in range(1, 33) for h in range(8 * p + 1)}
+
+
+class OracleTable:
+    def __init__(self, metric, key_words, max_bytes):
+        self.metric, self.key_words, self.max_bytes = metric, key_words, max_bytes
+        self.max_words = (max_bytes + 7) // 8
+        self._rows = {}  # key tuple -> (words tuple, nbytes)
+        self.engine = None
+
+    @staticmethod
+    def _kt(k):
+        return tuple(int(x) for x in np.atleast_1d(k))
+
+    def add(self, keys, words, nbytes=None, trusted_unique=False):
+        keys = np.asarray(keys, dtype=np.uint64)
+        words = np.asarray(words, dtype=np.uint64)
+        n = keys.shape[0]
+        kts = [self._kt(keys[i]) for i in range(n)]
+        if not trusted_unique:
+            if len(set(kts)) != n or any(k in self._rows for k in kts):
+                raise KeyError("key already present")
+        for i, k in enumerate(kts):
+            nb = int(nbytes[i]) if nbytes is not None else self.max_bytes
+            if self.metric == 0 and nb != self.max_bytes:
+                raise ValueError("Hamming table holds fixed-length codes")
+            self._rows[k] = (words[i].copy(), nb)
+
+    def remove(self, keys):
+        keys = np.asarray(keys, dtype=np.uint64)
+        removed = 0
+        for i in range(keys.shape[0]):
+            if self._rows.pop(self._kt(keys[i]), None) is not None:
+                removed += 1
+        return removed
+
+    def contains(self, keys):
+        keys = np.asarray(keys, dtype=np.uint64)
+        return np.array([self._kt(keys[i]) in self._rows for i in range(keys.shape[0])], dtype=bool)
+
+    def get(self, keys):
+        keys = np.asarray(keys, dtype=np.uint64)
+        n = keys.shape[0]
+        words = np.zeros((n, self.max_words), dtype=np.uint64)
+        nb = np.zeros(n, dtype=np.uint8)
+        for i in range(n):
+            row = self._rows.get(self._kt(keys[i]))
+            if row is not None:
+                words[i], nb[i] = row
+        return words, nb
+
+    @property
+    def size(self):
+        return len(self._rows)
+
+    def _arrays(self):
+        n = len(self._rows)
+        keys = np.zeros((n, 2) if self.key_words == 2 else n, dtype=np.uint64)
+        words = np.zeros((n, self.max_words), dtype=np.uint64)
+        nb = np.zeros(n, dtype=np.uint8)
+        for i, (k, (w, b)) in enumerate(self._rows.items()):
+            keys[i] = k if self.key_words == 2 else k[0]
+            words[i] = w
+            nb[i] = b
+        return keys, words, nb
+
+    def search(self, q_words, q_nbytes, k):
+        if k < 1:
+            raise ValueError("`count` must be >= 1")
+        q_words = np.asarray(q_words, dtype=np.uint64)
+        nq = q_words.shape[0]
+        keys, words, nb = self._arrays()
+        if self.metric == 0:
+            return oracle_topk(0, keys, words, None, q_words, None, k, fixed_nbytes=self.max_bytes)
+        if q_nbytes is None:
+            raise ValueError("nbytes is required for NPHD tables")
+        if len(self._rows) == 0:
+            shape = (nq, k, 2) if self.key_words == 2 else (nq, k)
+            return np.zeros(shape, np.uint64), np.zeros((nq, k), np.uint32), np.zeros((nq, k), np.uint16), np.zeros(nq, np.uint32)
+        return oracle_topk(1, keys, words, nb, q_words, np.asarray(q_nbytes, dtype=np.uint8), k)
+
+    def search_records(self, q_words, q_nbytes, k):
+        """Structured records [nq, k] + counts, as the device exchange format."""
+        keys, ham, pbits, cnt = self.search(q_words, q_nbytes, k)
+        ranks = rank_table()
+        nq = q_words.shape[0]
+        rec = np.zeros((nq, k), dtype=RECORD_DTYPE)
+        for q in range(nq):
+            for i in range(int(cnt[q])):
+                if self.key_words == 2:
+                    rec[q, i]["key_hi"], rec[q, i]["key_lo"] = keys[q, i, 0], keys[q, i, 1]
+                else:
+                    rec[q, i]["key_lo"] = keys[q, i]
+                h, p = int(ham[q, i]), int(pbits[q, i])
+                rec[q, i]["hamming"], rec[q, i]["prefix_bits"] = h, p
+                rec[q, i]["dist_rank"] = ranks[(p // 8, h)] if self.metric == 1 else h
+        return rec, cnt.astype(np.int32)
+
+    def drop(self):
+        self._rows.clear()
+
+
+class OracleEngine:
+    def open_table(self, metric, key_words, max_bytes):
+        t = OracleTable(metric, key_words, max_bytes)
+        t.engine = self
+        return t
+
+    def close(self):
+        pass

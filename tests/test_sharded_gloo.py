@@ -1,0 +1,140 @@
+"""
+Multi-process (world_size 2, gloo, CPU) cover of the row-sharded search path:
+``ShardedTable`` = local exact top-k per shard -> ONE all-gather of {records | counts} blocks ->
+k-way merge, identical on every rank and identical to the unsharded oracle answer.
+The device kernels are replaced by the oracle-backed ops object; the exchange layout, the shard
+arithmetic and the collective call are the product code (``iscc_search_amd/sharded.py``).
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from iscc_search_amd.sharded import RECORD_BYTES, ShardedTable, block_bytes, shard_of_key, shard_range
+from oracle import oracle_topk
+from oracle_engine import RECORD_DTYPE, OracleTable
+
+
+class OracleShardOps:
+    """CPU stand-in for HipShardOps with the same block layout."""
+
+    def __init__(self, table):
+        self.table = table
+        self.key_words = table.key_words
+
+    def local_search(self, q_words, q_nbytes, k):
+        rec, cnt = self.table.search_records(q_words, q_nbytes, k)
+        nq = q_words.shape[0]
+        rec_bytes, blk = block_bytes(nq, k)
+        buf = np.zeros(blk, dtype=np.uint8)
+        buf[:rec_bytes] = rec.reshape(-1).view(np.uint8)
+        buf[rec_bytes : rec_bytes + nq * 4] = cnt.astype("<i4").view(np.uint8)
+        return torch.from_numpy(buf)
+
+    def merge(self, gathered, n_lists, nq, k):
+        rec_bytes, blk = block_bytes(nq, k)
+        raw = gathered.numpy()
+        entries = [[] for _ in range(nq)]
+        for l in range(n_lists):
+            block = raw[l * blk : (l + 1) * blk]
+            rec = block[:rec_bytes].view(RECORD_DTYPE).reshape(nq, k)
+            cnt = block[rec_bytes : rec_bytes + nq * 4].view("<i4")
+            for q in range(nq):
+                for i in range(int(cnt[q])):
+                    r = rec[q, i]
+                    entries[q].append((int(r["dist_rank"]), int(r["key_hi"]), int(r["key_lo"]), int(r["hamming"]), int(r["prefix_bits"])))
+        shape = (nq, k, 2) if self.key_words == 2 else (nq, k)
+        keys = np.zeros(shape, np.uint64)
+        ham = np.zeros((nq, k), np.uint32)
+        pb = np.zeros((nq, k), np.uint16)
+        out_cnt = np.zeros(nq, np.uint32)
+        for q in range(nq):
+            top = sorted(entries[q])[:k]
+            out_cnt[q] = len(top)
+            for i, (_, hi, lo, h, p) in enumerate(top):
+                if self.key_words == 2:
+                    keys[q, i] = (hi, lo)
+                else:
+                    keys[q, i] = lo
+                ham[q, i], pb[q, i] = h, p
+        return keys, ham, pb, out_cnt
+
+
+def _dataset(metric):
+    rng = np.random.default_rng(123)
+    n = 4000
+    if metric == 1:
+        lens = rng.choice([8, 16, 32], size=n).astype(np.uint8)
+        words = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+        for j in range(4):
+            words[lens.astype(np.int64) <= 8 * j, j] = 0
+        q = words[[3, 99, 2500]].copy()
+        q[:, 0] ^= np.uint64(5)
+        qlens = lens[[3, 99, 2500]].copy()
+    else:
+        lens = None
+        words = rng.integers(0, 8, size=(n, 1), dtype=np.uint64)        # tiny code space: massive ties across shards
+        q = np.array([[1], [6], [3]], dtype=np.uint64)
+        qlens = None
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(17)
+    return keys, words, lens, q, qlens
+
+
+def _worker(rank, world, port, metric, routing, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys, words, lens, q, qlens = _dataset(metric)
+        n = len(keys)
+        if routing == "range":
+            lo, hi = shard_range(n, rank, world)
+            mine = np.arange(lo, hi)
+        else:
+            mine = np.array([i for i in range(n) if shard_of_key(int(keys[i]), world) == rank])
+        table = OracleTable(metric, 1, 32 if metric == 1 else 8)
+        table.add(keys[mine], words[mine], None if lens is None else lens[mine])
+        sharded = ShardedTable(OracleShardOps(table))
+        assert (sharded.rank, sharded.world_size) == (rank, world)
+        got = sharded.search(q, qlens, 12)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), *got)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("metric,routing", [(0, "range"), (1, "range"), (1, "hash")])
+def test_two_rank_sharded_search_equals_unsharded_oracle(tmp_path, metric, routing):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), metric, routing, str(tmp_path)), nprocs=world, join=True)
+    keys, words, lens, q, qlens = _dataset(metric)
+    exp = oracle_topk(metric, keys, words, lens, q, qlens, 12, fixed_nbytes=8 if metric == 0 else 0)
+    results = []
+    for r in range(world):
+        with np.load(os.path.join(tmp_path, f"r{r}.npz")) as z:
+            results.append([z[f"arr_{i}"] for i in range(4)])
+    for got in results:                      # every rank holds the same, exact, global answer
+        for g, e in zip(got, exp):
+            np.testing.assert_array_equal(g, e)
+
+
+def test_shard_arithmetic():
+    for n in (0, 1, 7, 100, 10**8 + 3):
+        for world in (1, 2, 3, 8):
+            ranges = [shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert block_bytes(3, 5) == (3 * 5 * RECORD_BYTES, 3 * 5 * RECORD_BYTES + 16)
+    assert {shard_of_key(k, 8) for k in range(1000)} == set(range(8))
