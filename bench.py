@@ -150,6 +150,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected x2
+    # for gfx950's half-count of 16 B/lane streams): bytes per pass for this workload, scaled to one launch.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size_scan_tq8.json")) as f:
+            pmc = json.load(f)
+        if args.rows == 100_000_000 and args.nbytes == 8 and world == 1 and st["scan_launches"]:
+            traffic = pmc["corrected_bytes_per_pass"] * st["scan_passes"] / st["scan_launches"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     total_queries = args.queries * args.steps
     qps = total_queries / elapsed
     achieved = (st["scan_bytes"] / 1e9) / (st["scan_ms"] / 1e3) if st["scan_ms"] > 0 else None
@@ -184,7 +195,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_fetch_size_scan_tq8.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)" if traffic else None,
             "launches": st["scan_launches"],
             "avg_launch_ms": (st["scan_ms"] / st["scan_launches"]) if st["scan_launches"] else None,
             "algorithmic_bytes_per_launch": (st["scan_bytes"] / st["scan_launches"]) if st["scan_launches"] else None,
