@@ -120,6 +120,7 @@ struct isccsearch_handle {
     int tq = 8;   // queries per streaming pass: 8 keeps the scan HBM-bound
     bool profile = false;
     bool nontemporal = true;
+    uint32_t blocks_per_cu = 8;    // scan grid = CUs x this (per query group)
     uint64_t boot_rows = 16384;    // rows of the threshold bootstrap (exact histogram per query)
     uint64_t sample_div = 1024;    // sample ~ n*k/sample_div rows -> ~sample_div candidates per query
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
@@ -238,6 +239,8 @@ template <int W, bool MASK>
 void launch_scan_tq(int tq, int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     switch (tq) {
         case 8: launch_scan_mode<W, MASK, 8>(mode, nt, grid, st, p); break;
+        case 10: launch_scan_mode<W, MASK, 10>(mode, nt, grid, st, p); break;
+        case 12: launch_scan_mode<W, MASK, 12>(mode, nt, grid, st, p); break;
         case 32: launch_scan_mode<W, MASK, 32>(mode, nt, grid, st, p); break;
         default: launch_scan_mode<W, MASK, 16>(mode, nt, grid, st, p); break;
     }
@@ -263,7 +266,7 @@ int tile_rows_for(int W) { return W == 1 ? isk::tile_rows<1>() : W == 2 ? isk::t
 // prologue (queries -> SGPRs) and the load pipeline are amortised.
 uint32_t scan_grid_x(H* h, int W, uint64_t rows, uint32_t groups = 1, bool sample = false) {
     const uint64_t tiles = rows / (uint64_t)tile_rows_for(W);
-    uint64_t maxb = (uint64_t)h->cus * 8;
+    uint64_t maxb = (uint64_t)h->cus * h->blocks_per_cu;
     if (sample) maxb = std::max<uint64_t>(8, maxb / std::max<uint32_t>(1, groups));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, maxb));
 }
@@ -571,13 +574,14 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!h || !name) return fail(-EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(name, "queries_per_pass")) {
-        if (value != 8 && value != 16 && value != 32) return fail(-EINVAL, "queries_per_pass must be 8, 16 or 32");
+        if (value != 8 && value != 10 && value != 12 && value != 16 && value != 32) return fail(-EINVAL, "queries_per_pass must be 8, 10, 12, 16 or 32");
         h->tq = (int)value;
         h->stats.queries_per_pass = (uint32_t)value;
         return 0;
     }
     if (!strcmp(name, "profile")) { h->profile = value != 0; return 0; }
     if (!strcmp(name, "nontemporal")) { h->nontemporal = value != 0; return 0; }
+    if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(-EINVAL, "blocks_per_cu must be 1..64"); h->blocks_per_cu = (uint32_t)value; return 0; }
     if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_div")) { if (value < 64 || value > 8192) return fail(-EINVAL, "sample_div must be 64..8192"); h->sample_div = (uint64_t)value; return 0; }
     return fail(-EINVAL, "unknown option '%s'", name);

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench): latency, small tables, large k, mixed lengths.
+
+  python tools/bench_misc.py [latency] [small] [simprint] [mixed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from iscc_search_amd import _lib  # noqa: E402
+from iscc_search_amd.engine import HipEngine  # noqa: E402
+
+
+def timeit(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    what = set(sys.argv[1:]) or {"latency", "small", "simprint", "mixed"}
+    eng = HipEngine(0)
+    rng = np.random.default_rng(0)
+    if "latency" in what:
+        t = eng.open_table(_lib.METRIC_HAMMING, 1, 8)
+        t.add_synthetic(8, 100_000_000, 1)
+        for nq in (1, 8, 16, 64):
+            q = rng.integers(0, 2**64, size=(nq, 1), dtype=np.uint64)
+            dt = timeit(lambda: t.search(q, None, 10))
+            print(f"latency: 100M x 64-bit, nq={nq:3d}, k=10: {dt*1e3:8.3f} ms/call  ({nq/dt:9.0f} qps)")
+        for k in (100, 1000, 4000):
+            q = rng.integers(0, 2**64, size=(16, 1), dtype=np.uint64)
+            dt = timeit(lambda: t.search(q, None, k), reps=5, warm=1)
+            print(f"large k: 100M x 64-bit, nq=16, k={k}: {dt*1e3:8.3f} ms/call")
+        t.drop()
+    if "small" in what:
+        for n in (10_000, 1_000_000, 10_000_000):
+            t = eng.open_table(_lib.METRIC_HAMMING, 1, 8)
+            t.add_synthetic(8, n, 2)
+            for nq in (1, 16, 1024):
+                q = rng.integers(0, 2**64, size=(nq, 1), dtype=np.uint64)
+                dt = timeit(lambda: t.search(q, None, 10))
+                print(f"small: {n:>10d} x 64-bit, nq={nq:4d}, k=10: {dt*1e3:8.3f} ms/call  ({nq/dt:10.0f} qps, {nq/8*n*8/dt/1e9:7.0f} GB/s algorithmic at T_q=8)")
+            t.drop()
+    if "simprint" in what:
+        # config 5: 10 M segments in three tables by ndim (64/128/256), 128-bit keys, count = 40 x limit
+        for nbytes, n in ((8, 4_000_000), (16, 4_000_000), (32, 2_000_000)):
+            t = eng.open_table(_lib.METRIC_HAMMING, 2, nbytes)
+            t.add_synthetic(nbytes, n, 3 + nbytes)
+            for nq, k in ((64, 400), (512, 400), (64, 4000)):
+                q = rng.integers(0, 2**64, size=(nq, t.max_words), dtype=np.uint64)
+                dt = timeit(lambda: t.search(q, None, k), reps=3, warm=1)
+                print(f"simprint: {n} x {nbytes*8}-bit (128-bit keys), nq={nq}, k={k}: {dt*1e3:9.3f} ms/call ({nq/dt:8.0f} qps)")
+            t.drop()
+    if "mixed" in what:
+        t = eng.open_table(_lib.METRIC_NPHD, 1, 32)
+        for nb, n in ((8, 40_000_000), (16, 20_000_000), (24, 10_000_000), (32, 30_000_000)):
+            t.add_synthetic(nb, n, 100 + nb, key_base=nb * 10**9)
+        for qb in (8, 32):
+            nq = 256
+            q = rng.integers(0, 2**64, size=(nq, 4), dtype=np.uint64)
+            for j in range(4):
+                if qb <= 8 * j:
+                    q[:, j] = 0
+            qn = np.full(nq, qb, dtype=np.uint8)
+            dt = timeit(lambda: t.search(q, qn, 10), reps=3, warm=1)
+            print(f"mixed NPHD: 100M rows in 4 length segments, {qb*8}-bit queries, nq={nq}, k=10: {dt*1e3:9.3f} ms/call ({nq/dt:8.0f} qps)")
+        t.drop()
+    print(eng.stats())
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
