@@ -16,6 +16,7 @@
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -121,8 +122,8 @@ struct isccsearch_handle {
     bool profile = false;
     bool nontemporal = true;
     uint32_t blocks_per_cu = 8;    // scan grid = CUs x this (per query group)
-    uint64_t boot_rows = 16384;    // rows of the threshold bootstrap (exact histogram per query)
-    uint64_t sample_div = 1024;    // sample ~ n*k/sample_div rows -> ~sample_div candidates per query
+    uint64_t boot_rows = 4096;     // rows of the threshold bootstrap (exact histogram per query)
+    uint64_t sample_cost = 100;    // relative cost (percent of a tile) of one candidate in a scan; sizes the last sample
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
     // scratch
@@ -260,14 +261,19 @@ void launch_scan(int W, bool mask, int tq, int mode, bool nt, dim3 grid, hipStre
 }
 int tile_rows_for(int W) { return W == 1 ? isk::tile_rows<1>() : W == 2 ? isk::tile_rows<2>() : W == 3 ? isk::tile_rows<3>() : isk::tile_rows<4>(); }
 
-// blocks per query group.  Full-table scans give every group the whole chip (groups run one after
-// the other, each streaming the table once).  Sample scans cover few tiles: spread the chip's
-// resident blocks over ALL groups so that each block walks several tiles and the per-block
-// prologue (queries -> SGPRs) and the load pipeline are amortised.
+// blocks per query group.
+//   Tables beyond the Infinity Cache (and their scans of every row): every group gets the whole
+//   chip, so groups run one after the other and each streams the table from HBM exactly once.
+//   Sample scans and cache-resident tables cover few tiles per group: spread the chip's resident
+//   blocks over ALL groups instead, so that each block walks several tiles (the per-block prologue
+//   -- queries -> SGPRs -- and the load pipeline are amortised) and concurrent groups share the
+//   cached rows.
+constexpr uint64_t CACHE_RESIDENT_BYTES = 128ull << 20;   // half of the 256 MiB Infinity Cache
 uint32_t scan_grid_x(H* h, int W, uint64_t rows, uint32_t groups = 1, bool sample = false) {
     const uint64_t tiles = rows / (uint64_t)tile_rows_for(W);
     uint64_t maxb = (uint64_t)h->cus * h->blocks_per_cu;
-    if (sample) maxb = std::max<uint64_t>(8, maxb / std::max<uint32_t>(1, groups));
+    if (sample || rows * 8 * (uint64_t)W <= CACHE_RESIDENT_BYTES)
+        maxb = std::max<uint64_t>(8, maxb / std::max<uint32_t>(1, groups));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, maxb));
 }
 
@@ -336,7 +342,7 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
     int rc;
     if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;
     if ((rc = h->d_bias.ensure(nq_pad))) return rc;
-    if ((rc = h->d_cnt.ensure(nq_pad))) return rc;
+    if ((rc = h->d_cnt.ensure((size_t)nq_pad * isk::CNT_STRIDE))) return rc;
     if ((rc = h->d_ghist.ensure((size_t)nq_pad * isk::HB))) return rc;
     if ((rc = h->d_overflow.ensure(nq_pad))) return rc;
     if ((rc = h->d_cand.ensure((size_t)nq_pad * cap))) return rc;
@@ -377,10 +383,14 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         sp.ghist = h->d_ghist.p; sp.cap = cap;
         sp.mask_lo = (uint32_t)j.mask_last; sp.mask_hi = (uint32_t)(j.mask_last >> 32);
 
-        // 2. sample scan: tighten the threshold to the k-th smallest of the first `sample` rows
-        const uint64_t want = (s.n / h->sample_div + 1) * (uint64_t)k;   // ~ n*k/sample_div rows -> ~sample_div candidates per query
-        const uint64_t sample = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, want));
-        if (sample > s0) {
+        // 2. sample scans: tighten the threshold level by level.  A scan of S rows under the threshold of
+        //    a sample of S' rows meets ~4096*k/S' candidates per wave-tile (each costs ~0.35 tile), so
+        //    every level grows the sample 8x, and the last level stops where its own cost balances the
+        //    candidate handling it saves the full scan: S_last ~ sqrt(0.35 * 4096 * k * n).
+        const double balance = std::sqrt((double)h->sample_cost / 100.0 * 4096.0 * (double)k * (double)s.n);
+        const uint64_t s_last = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, (uint64_t)balance));
+        for (uint64_t sample = s0; sample < s_last;) {
+            sample = std::min<uint64_t>(s_last, sample * 8);
             HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
             sp.n_rows = sample;
             launch_scan((int)j.W, j.mask, tq, isk::MODE_HIST, h->nontemporal, dim3(scan_grid_x(h, j.W, sample, groups, true), groups), h->stream, sp);
@@ -390,11 +400,11 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         }
 
         // 3. the streaming pass: collect every row within the threshold
-        HIPOK(hipMemsetAsync(h->d_cnt.p, 0, nq_pad * sizeof(uint32_t), h->stream));
+        HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
         sp.n_rows = s.n;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
-        launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), groups), h->stream, sp);
+        launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n, groups), groups), h->stream, sp);
         if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
         h->stats.scan_launches += 1;
         h->stats.scan_passes += groups;
@@ -441,13 +451,13 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
             std::vector<uint32_t> hb(tq, isk::BIAS_NEVER);
             hb[ql] = 0x7FFFFFFFu - tau;
             HIPOK(hipMemcpyAsync(h->d_bias.p + (size_t)g * tq, hb.data(), tq * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-            HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)g * tq, 0, tq * sizeof(uint32_t), h->stream));
+            HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE, 0, (size_t)tq * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
             isk::ScanParams fsp = sp;
             fsp.n_rows = s.n;
             fsp.cap = (uint32_t)cum;
             fsp.queries = h->d_queries.p + (size_t)g * tq * 4;
             fsp.bias = h->d_bias.p + (size_t)g * tq;
-            fsp.cnt = h->d_cnt.p + (size_t)g * tq;
+            fsp.cnt = h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE;
             // slot ql of the group appends at cand[ql*cap + i]: bias the base so that lands at d_misc2[i]
             fsp.cand = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)ql * fsp.cap * 8);
             launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), 1), h->stream, fsp);
@@ -583,7 +593,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "nontemporal")) { h->nontemporal = value != 0; return 0; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(-EINVAL, "blocks_per_cu must be 1..64"); h->blocks_per_cu = (uint32_t)value; return 0; }
     if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
-    if (!strcmp(name, "sample_div")) { if (value < 64 || value > 8192) return fail(-EINVAL, "sample_div must be 64..8192"); h->sample_div = (uint64_t)value; return 0; }
+    if (!strcmp(name, "sample_cost")) { if (value < 1 || value > 10000) return fail(-EINVAL, "sample_cost must be 1..10000"); h->sample_cost = (uint64_t)value; return 0; }
     return fail(-EINVAL, "unknown option '%s'", name);
 }
 

@@ -34,6 +34,8 @@ namespace isk {
 constexpr int BLOCK = 256;            // threads per workgroup = 4 waves of 64
 constexpr uint32_t HB = 264;          // histogram stride per query (bins 0..256 used)
 constexpr uint32_t NBINS = 257;       // hamming distance 0..256
+constexpr uint32_t CNT_STRIDE = 32;   // one candidate counter per 128-byte line: device-scope atomics on
+                                      // words of one line serialise at the memory side (~90 M/s per line)
 constexpr uint32_t BIT31 = 0x80000000u;
 constexpr uint32_t BIAS_NEVER = 0x80000000u;  // bias + h always has bit 31 set: never a candidate
 constexpr int MODE_COLLECT = 0;
@@ -57,7 +59,7 @@ struct ScanParams {
     uint64_t n_rows;          // rows [0, n_rows) are scanned
     const uint64_t* queries;  // [nq_pad][4] big-endian packed query words
     const uint32_t* bias;     // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries)
-    uint32_t* cnt;            // [nq_pad] candidates appended so far          (MODE_COLLECT)
+    uint32_t* cnt;            // [nq_pad * CNT_STRIDE] candidates appended so far (MODE_COLLECT)
     uint64_t* cand;           // [nq_pad][cap] (hamming << 48) | row          (MODE_COLLECT)
     uint32_t* ghist;          // [nq_pad][HB] histogram of hamming <= tau     (MODE_HIST)
     uint32_t cap;
@@ -111,7 +113,7 @@ __device__ __forceinline__ void wait_tile(u32x4 (&v)[U][W]) {
 template <int MODE>
 __device__ __forceinline__ void emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
     if constexpr (MODE == MODE_COLLECT) {
-        const uint32_t slot = atomicAdd(&p.cnt[qi], 1u);
+        const uint32_t slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
         if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)h << 48) | row;
     } else {
         atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
@@ -156,7 +158,9 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
     auto load_tile = [&](u32x4 (&v)[U][W], uint64_t tile) {
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            const char* tb = reinterpret_cast<const char*>(p.col[w]) + tile * (uint64_t)(TILE * 8);   // uniform
+            // uniform tile base, forced into an SGPR pair for the saddr operand
+            const uint64_t ta = reinterpret_cast<uint64_t>(p.col[w]) + tile * (uint64_t)(TILE * 8);
+            const char* tb = reinterpret_cast<const char*>(((uint64_t)sgpr((uint32_t)(ta >> 32)) << 32) | sgpr((uint32_t)ta));
 #pragma unroll
             for (int u = 0; u < U; ++u) gload16<NT>(v[u][w], tb, voff[u]);
         }
@@ -183,31 +187,43 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
             }
         }
         if ((int32_t)m >= 0) {
-            // rare: at least one (row, query) pair of this lane is within its threshold
+            // rare: at least one (row, query) pair of this lane is within its threshold.  Rescore per
+            // query from the SGPR-resident queries (fully unrolled: no memory loads, no dynamic register
+            // indexing), so a tile that takes this path costs about two plain tiles instead of the
+            // ~16 a load-per-query loop cost.
             const uint64_t base = tile * TILE + (uint64_t)tid * 2;
-#pragma unroll 1
-            for (int q = 0; q < TQ; ++q) {
-                const uint32_t b = p.bias[q0 + q];
-                uint32_t sl[W], sh[W];
+            // launder the row registers: without this the compiler merges the rescoring below with
+            // the fast path above (common subexpressions) and keeps all TQ*U*2 accumulators alive
+            u32x4 r[U][W];
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    const uint64_t qq = p.queries[(uint64_t)(q0 + q) * 4 + w];
-                    sl[w] = (uint32_t)qq; sh[w] = (uint32_t)(qq >> 32);
-                }
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int w = 0; w < W; ++w) { r[u][w] = v[u][w]; asm volatile("" : "+v"(r[u][w])); }
+#pragma unroll
+            for (int q = 0; q < TQ; ++q) {
+                uint32_t a[U][2];
+                uint32_t mq = 0xFFFFFFFFu;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    uint32_t a0 = b, a1 = b;
+                    uint32_t a0 = bias[q], a1 = bias[q];
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
-                        uint32_t x0 = v[u][w].x ^ sl[w], y0 = v[u][w].y ^ sh[w];
-                        uint32_t x1 = v[u][w].z ^ sl[w], y1 = v[u][w].w ^ sh[w];
+                        uint32_t x0 = r[u][w].x ^ qlo[q][w], y0 = r[u][w].y ^ qhi[q][w];
+                        uint32_t x1 = r[u][w].z ^ qlo[q][w], y1 = r[u][w].w ^ qhi[q][w];
                         if (MASK && w == W - 1) { x0 &= mlo; y0 &= mhi; x1 &= mlo; y1 &= mhi; }
                         a0 = bcnt(y0, bcnt(x0, a0));
                         a1 = bcnt(y1, bcnt(x1, a1));
                     }
-                    const uint64_t row = base + (uint64_t)u * (BLOCK * 2);
-                    if ((int32_t)a0 >= 0) emit<MODE>(p, q0 + q, a0 - b, row);
-                    if ((int32_t)a1 >= 0) emit<MODE>(p, q0 + q, a1 - b, row + 1);
+                    a[u][0] = a0; a[u][1] = a1;
+                    mq = min(mq, min(a0, a1));
+                }
+                if ((int32_t)mq >= 0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint64_t row = base + (uint64_t)u * (BLOCK * 2);
+                        if ((int32_t)a[u][0] >= 0) emit<MODE>(p, q0 + q, a[u][0] - bias[q], row);
+                        if ((int32_t)a[u][1] >= 0) emit<MODE>(p, q0 + q, a[u][1] - bias[q], row + 1);
+                    }
                 }
             }
         }
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void pick_kernel(const PickParams p) {
 // dynamic LDS: sh[P] u32 | pad | klo[P] u64 | khi[P] u64 (KW == 2)
 // ---------------------------------------------------------------------------------------------
 struct SelectParams {
-    const uint32_t* cnt;      // [nq_pad]
+    const uint32_t* cnt;      // [nq_pad * CNT_STRIDE]
     const uint64_t* cand;     // [nq_pad][cap]
     uint64_t cap;
     const uint64_t* keys;     // segment key column [rows*KW]
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
 
     const uint32_t tid = threadIdx.x;
     const uint32_t q = p.q_base + blockIdx.x;
-    const uint32_t total = p.cnt[q];
+    const uint32_t total = p.cnt[(uint64_t)q * CNT_STRIDE];
     if (total > p.cap) {             // candidate list overflowed: host reruns this query exactly
         if (tid == 0) { p.overflow[q] = 1; p.out_count[q] = 0; }
         return;

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""One configurable search loop for profiling: python tools/bench_one.py ROWS NBYTES NQ K [REPS] [KEYWORDS]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from iscc_search_amd import _lib  # noqa: E402
+from iscc_search_amd.engine import HipEngine  # noqa: E402
+
+rows, nbytes, nq, k = (int(x) for x in sys.argv[1:5])
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+kw = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+eng = HipEngine(0)
+t = eng.open_table(_lib.METRIC_HAMMING, kw, nbytes)
+t.add_synthetic(nbytes, rows, 7)
+q = np.random.default_rng(0).integers(0, 2**64, size=(nq, t.max_words), dtype=np.uint64)
+t.search(q, None, k)
+t0 = time.perf_counter()
+for _ in range(reps):
+    t.search(q, None, k)
+dt = (time.perf_counter() - t0) / reps
+print(f"{rows} x {nbytes*8}-bit, nq={nq}, k={k}: {dt*1e3:.3f} ms/call, {nq/dt:.0f} qps")
+eng.close()
