@@ -344,7 +344,7 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
     if ((rc = h->d_bias.ensure(nq_pad))) return rc;
     if ((rc = h->d_cnt.ensure((size_t)nq_pad * isk::CNT_STRIDE))) return rc;
     if ((rc = h->d_ghist.ensure((size_t)nq_pad * isk::HB))) return rc;
-    if ((rc = h->d_overflow.ensure(nq_pad))) return rc;
+    if ((rc = h->d_overflow.ensure((size_t)nq_pad * 33))) return rc;
     if ((rc = h->d_cand.ensure((size_t)nq_pad * cap))) return rc;
     const bool multi = jobs.size() > 1;
     if (multi) {
@@ -358,17 +358,40 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         for (int w = 0; w < t.max_words; ++w) stage[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
     HIPOK(hipMemcpyAsync(h->d_queries.p, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPOK(hipStreamSynchronize(h->stream));   // `stage` is pageable host memory about to go out of scope
-    HIPOK(hipMemsetAsync(h->d_overflow.p, 0, nq_pad * sizeof(uint32_t), h->stream));
+    HIPOK(hipMemsetAsync(h->d_overflow.p, 0, (size_t)nq_pad * jobs.size() * sizeof(uint32_t), h->stream));
 
     const uint32_t P = next_pow2(k);
     const size_t sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
 
-    std::vector<uint32_t> job_overflow;
+    // per-job kernel arguments
+    struct Ctx { isk::ScanParams sp; isk::SelectParams sl; };
+    auto make_ctx = [&](size_t ji) {
+        const Job& j = jobs[ji];
+        Segment& s = *j.seg;
+        Ctx c{};
+        for (uint32_t w = 0; w < j.W; ++w) c.sp.col[w] = s.col[w];
+        c.sp.queries = h->d_queries.p; c.sp.bias = h->d_bias.p; c.sp.cnt = h->d_cnt.p; c.sp.cand = h->d_cand.p;
+        c.sp.ghist = h->d_ghist.p; c.sp.cap = cap;
+        c.sp.mask_lo = (uint32_t)j.mask_last; c.sp.mask_hi = (uint32_t)(j.mask_last >> 32);
+        c.sl.cnt = h->d_cnt.p; c.sl.cand = h->d_cand.p; c.sl.cap = cap; c.sl.keys = s.keys;
+        c.sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
+        c.sl.out = multi ? h->d_lists.p + ji * (size_t)nq * k : d_out;
+        c.sl.out_count = multi ? h->d_listcnt.p + ji * (size_t)nq : d_out_cnt;
+        c.sl.overflow = h->d_overflow.p + ji * (size_t)nq_pad;
+        c.sl.k = k; c.sl.P = P; c.sl.prefix_bits = j.pbytes * 8; c.sl.q_base = 0;
+        return c;
+    };
+    auto launch_select = [&](const isk::SelectParams& sl, uint32_t blocks) {
+        if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+        else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+    };
+
+    // ---- every job, back to back on the stream, no host synchronisation ----
     for (size_t ji = 0; ji < jobs.size(); ++ji) {
         const Job& j = jobs[ji];
         Segment& s = *j.seg;
-        isk::Record* out = multi ? h->d_lists.p + ji * (size_t)nq * k : d_out;
-        uint32_t* out_cnt = multi ? h->d_listcnt.p + ji * (size_t)nq : d_out_cnt;
+        Ctx c = make_ctx(ji);
+        isk::ScanParams& sp = c.sp;
 
         // 1. bootstrap threshold from the first s0 rows
         const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
@@ -377,16 +400,10 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
         hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
 
-        isk::ScanParams sp{};
-        for (uint32_t w = 0; w < j.W; ++w) sp.col[w] = s.col[w];
-        sp.queries = h->d_queries.p; sp.bias = h->d_bias.p; sp.cnt = h->d_cnt.p; sp.cand = h->d_cand.p;
-        sp.ghist = h->d_ghist.p; sp.cap = cap;
-        sp.mask_lo = (uint32_t)j.mask_last; sp.mask_hi = (uint32_t)(j.mask_last >> 32);
-
         // 2. sample scans: tighten the threshold level by level.  A scan of S rows under the threshold of
-        //    a sample of S' rows meets ~4096*k/S' candidates per wave-tile (each costs ~0.35 tile), so
-        //    every level grows the sample 8x, and the last level stops where its own cost balances the
-        //    candidate handling it saves the full scan: S_last ~ sqrt(0.35 * 4096 * k * n).
+        //    a sample of S' rows meets ~4096*k/S' candidates per wave-tile (each costs a fraction of a
+        //    tile), so every level grows the sample 8x, and the last level stops where its own cost
+        //    balances the candidate handling it saves the full scan: S_last ~ sqrt(cost * 4096 * k * n).
         const double balance = std::sqrt((double)h->sample_cost / 100.0 * 4096.0 * (double)k * (double)s.n);
         const uint64_t s_last = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, (uint64_t)balance));
         for (uint64_t sample = s0; sample < s_last;) {
@@ -410,23 +427,23 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         h->stats.scan_passes += groups;
         h->stats.scan_bytes += s.n * 8 * j.W * groups;
 
-        // 4. exact select of the k best candidates per query
-        isk::SelectParams sl{};
-        sl.cnt = h->d_cnt.p; sl.cand = h->d_cand.p; sl.cap = cap; sl.keys = s.keys;
-        sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
-        sl.out = out; sl.out_count = out_cnt; sl.overflow = h->d_overflow.p; sl.k = k; sl.P = P;
-        sl.prefix_bits = j.pbytes * 8; sl.q_base = 0;
-        if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(nq), dim3(isk::BLOCK), sel_lds, h->stream, sl);
-        else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(nq), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+        // 4. exact select of the k best candidates per query (flags candidate-list overflow)
+        launch_select(c.sl, nq);
         HIPOK(hipGetLastError());
+    }
 
-        // 5. overflow check (one small copy per job; almost always all zero)
-        h->h_overflow.resize(nq);
-        HIPOK(hipMemcpyAsync(h->h_overflow.data(), h->d_overflow.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPOK(hipStreamSynchronize(h->stream));
+    // ---- ONE overflow check for all jobs (a small copy; almost always all zero) ----
+    h->h_overflow.resize((size_t)jobs.size() * nq_pad);
+    HIPOK(hipMemcpyAsync(h->h_overflow.data(), h->d_overflow.p, h->h_overflow.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    for (size_t ji = 0; ji < jobs.size(); ++ji) {
+        const Job& j = jobs[ji];
+        Segment& s = *j.seg;
         for (uint32_t q = 0; q < nq; ++q) {
-            if (!h->h_overflow[q]) continue;
-            // exact fallback for this query on this segment
+            if (!h->h_overflow[ji * nq_pad + q]) continue;
+            // exact fallback for this query on this segment: full histogram -> exact threshold ->
+            // collect into a buffer sized to the tie class -> select
+            Ctx c = make_ctx(ji);
             h->stats.fallback_queries += 1;
             if ((rc = h->d_misc.ensure(isk::HB + 8))) return rc;
             uint32_t* d_fh = reinterpret_cast<uint32_t*>(h->d_misc.p);
@@ -452,7 +469,7 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
             hb[ql] = 0x7FFFFFFFu - tau;
             HIPOK(hipMemcpyAsync(h->d_bias.p + (size_t)g * tq, hb.data(), tq * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
             HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE, 0, (size_t)tq * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
-            isk::ScanParams fsp = sp;
+            isk::ScanParams fsp = c.sp;
             fsp.n_rows = s.n;
             fsp.cap = (uint32_t)cum;
             fsp.queries = h->d_queries.p + (size_t)g * tq * 4;
@@ -462,13 +479,12 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
             fsp.cand = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)ql * fsp.cap * 8);
             launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), 1), h->stream, fsp);
             HIPOK(hipStreamSynchronize(h->stream));   // hb is pageable host memory
-            isk::SelectParams fsl = sl;
+            isk::SelectParams fsl = c.sl;
             fsl.cnt = h->d_cnt.p; fsl.cap = fsp.cap; fsl.q_base = q;
             fsl.cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)q * fsp.cap * 8);
             // reset the overflow flag of q so a second overflow would be seen
-            HIPOK(hipMemsetAsync(h->d_overflow.p + q, 0, sizeof(uint32_t), h->stream));
-            if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(1), dim3(isk::BLOCK), sel_lds, h->stream, fsl);
-            else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(1), dim3(isk::BLOCK), sel_lds, h->stream, fsl);
+            HIPOK(hipMemsetAsync(c.sl.overflow + q, 0, sizeof(uint32_t), h->stream));
+            launch_select(fsl, 1);
             HIPOK(hipGetLastError());
             HIPOK(hipStreamSynchronize(h->stream));
         }
