@@ -66,6 +66,16 @@ def load_library():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C iscc_search_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1
+    # under the same sonames as /opt/rocm's; whichever is loaded first serves every later DT_NEEDED.
+    # If this library pulled in /opt/rocm's copy first, a later `import torch` would initialise against
+    # a runtime it was not built for ("No HIP GPUs are available").  So when torch is installed, let it
+    # load its runtime first and share it (set ISCC_HIP_NO_TORCH=1 for a torch-free process).
+    if not os.environ.get("ISCC_HIP_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host

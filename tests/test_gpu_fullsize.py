@@ -1,0 +1,148 @@
+"""
+BASELINE-size checks on the GPU (100 M x 64-bit, the configuration the metric is quoted on).
+
+At this size the oracle can only afford a handful of queries, so parity is shown three ways:
+  * bit-exact against the oracle for a few queries over all 100 M rows
+  * size-independent properties for every query: planted neighbours come back first with their
+    closed-form distance, lists are sorted by (distance, key), counts equal k, calls are idempotent,
+    T_q = 8 and T_q = 16 kernels agree, and a 2-shard split merged by merge_kernel equals the unsharded answer
+  * (small sizes are covered exhaustively in test_gpu_parity.py)
+"""
+
+import numpy as np
+import pytest
+
+from oracle import oracle_splitmix64_fill, oracle_topk
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 100_000_000
+SEED = 0x1511CC00
+K = 10
+
+
+def _queries(nq):
+    rng = np.random.default_rng(99)
+    q = rng.integers(0, 2**64, size=(nq, 1), dtype=np.uint64)
+    planted = {}
+    for j in range(0, nq, 4):
+        r = int(rng.integers(0, ROWS))
+        f = (0, 1, 3, 7)[(j // 4) % 4]
+        code = int(oracle_splitmix64_fill(1, SEED, first=r, stride=4)[0])
+        q[j, 0] = np.uint64(code ^ f)
+        planted[j] = (r, bin(f).count("1"))
+    return q, planted
+
+
+@pytest.fixture(scope="module")
+def big(hip_engine):
+    t = hip_engine.open_table(0, 1, 8)
+    t.add_synthetic(8, ROWS, SEED)
+    yield t
+    t.drop()
+
+
+def test_fullsize_properties_and_oracle_spot_check(hip_engine, big):
+    q, planted = _queries(64)
+    keys, ham, pbits, cnt = big.search(q, None, K)
+    assert np.all(cnt == K) and np.all(pbits == 64)
+    # sorted by (distance, key)
+    for i in range(q.shape[0]):
+        pairs = list(zip(ham[i].tolist(), keys[i].tolist()))
+        assert pairs == sorted(pairs)
+        assert len(set(keys[i].tolist())) == K
+    # planted neighbours: key = row number, distance = flipped bits (a closer random row is astronomically unlikely)
+    for j, (r, f) in planted.items():
+        assert int(ham[j, 0]) == f and int(keys[j, 0]) == r, (j, ham[j, :3], keys[j, :3])
+    # idempotent
+    again = big.search(q, None, K)
+    for a, b in zip((keys, ham, pbits, cnt), again):
+        np.testing.assert_array_equal(a, b)
+    # the VALU-bound T_q = 16 kernel returns the same bits
+    hip_engine.set_option("queries_per_pass", 16)
+    try:
+        other = big.search(q, None, K)
+    finally:
+        hip_engine.set_option("queries_per_pass", 8)
+    for a, b in zip((keys, ham, pbits, cnt), other):
+        np.testing.assert_array_equal(a, b)
+    # bit-exact against the oracle over all 100 M rows for a few queries (one planted, rest random)
+    words = oracle_splitmix64_fill(ROWS, SEED, stride=4).reshape(ROWS, 1)
+    row_keys = np.arange(ROWS, dtype=np.uint64)
+    pick = [0, 1, 2, 7, 13, 33]
+    exp = oracle_topk(0, row_keys, words, None, q[pick], None, K)
+    np.testing.assert_array_equal(keys[pick], exp[0])
+    np.testing.assert_array_equal(ham[pick], exp[1])
+    np.testing.assert_array_equal(cnt[pick], exp[3])
+
+
+def test_two_shards_merged_on_device_equal_the_unsharded_answer(hip_engine, big):
+    """Row-range shards [0, N/2) and [N/2, N) as two tables; their device-resident top-k merged by merge_kernel."""
+    import torch
+
+    from iscc_search_amd.sharded import block_bytes
+
+    q, _ = _queries(32)
+    nq = q.shape[0]
+    whole = big.search(q, None, K)
+    half = ROWS // 2
+    shards = []
+    for lo, hi in ((0, half), (half, ROWS)):
+        t = hip_engine.open_table(0, 1, 8)
+        t.add_synthetic(8, hi - lo, SEED, first_row=lo)
+        shards.append(t)
+    try:
+        rec_bytes, blk = block_bytes(nq, K)
+        gathered = torch.empty(2 * blk, dtype=torch.uint8, device="cuda:0")
+        for i, t in enumerate(shards):
+            base = gathered.data_ptr() + i * blk
+            t.search_device(q, None, K, base, base + rec_bytes)
+        torch.cuda.synchronize()
+        merged = hip_engine.merge_device(2, nq, K, 1, gathered.data_ptr(), gathered.data_ptr() + rec_bytes, blk, blk)
+        for a, b in zip(whole, merged):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        for t in shards:
+            t.drop()
+
+
+def test_concurrent_searches_and_adds_are_serialised_safely(hip_engine):
+    """The reference is called from a thread pool (docs/explanation/architecture.md:120-126)."""
+    import threading
+
+    rng = np.random.default_rng(5)
+    n = 200_000
+    t = hip_engine.open_table(0, 1, 8)
+    words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+    keys = np.arange(n, dtype=np.uint64)
+    t.add(keys, words)
+    q = words[:32] ^ np.uint64(1)
+    expected = t.search(q, None, 5)
+    errors = []
+
+    def searcher():
+        try:
+            for _ in range(20):
+                got = t.search(q, None, 5)
+                # rows added meanwhile are far away in Hamming space with overwhelming probability;
+                # the exact neighbours of q stay in front
+                np.testing.assert_array_equal(got[0][:, 0], expected[0][:, 0])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    def adder():
+        try:
+            for i in range(10):
+                m = 1000
+                t.add(np.arange(n + i * m, n + (i + 1) * m, dtype=np.uint64), rng.integers(0, 2**64, size=(m, 1), dtype=np.uint64))
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=searcher) for _ in range(4)] + [threading.Thread(target=adder)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert t.size == n + 10_000
+    t.drop()
