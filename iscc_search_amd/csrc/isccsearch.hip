@@ -103,6 +103,24 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+template <typename T>
+struct PinBuf {   // page-locked host memory: async copies really are asynchronous
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t need) {
+        if (need <= n) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+        size_t want = need + need / 4 + 16;
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(-ENOMEM, "hipHostMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+        n = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
 uint64_t mask_for(uint32_t pbytes) {   // mask of the last compared word for a prefix of pbytes bytes
     const uint32_t rem = pbytes & 7;
     return rem ? ~0ULL << (8 * (8 - rem)) : ~0ULL;
@@ -131,6 +149,9 @@ struct isccsearch_handle {
     DevBuf<uint32_t> d_bias, d_cnt, d_ghist, d_overflow, d_listcnt, d_outcnt;
     DevBuf<uint64_t> d_cand;
     DevBuf<isk::Record> d_lists, d_final;
+    PinBuf<uint64_t> p_queries;     // pinned staging: queries in, flags / results out
+    PinBuf<uint32_t> p_flags, p_cnt;
+    PinBuf<isk::Record> p_final;
     DevBuf<uint64_t> d_misc;        // moves / gather rows / single query
     DevBuf<uint64_t> d_misc2;
     std::vector<isk::Record> h_final;
@@ -305,6 +326,10 @@ int drain_events(H* h) {
 
 // ------------------------------------------------------------------------------------------
 // the search pipeline for one batch (<= QB_MAX) of equal-length queries
+//   begin()  every (segment) job back to back on the stream, no host synchronisation
+//   flags    one small device->host copy tells which queries overflowed their candidate list
+//   fix()    exact fallback for those (rare)
+//   merge()  k-way merge of the per-segment lists when the table has more than one segment
 // ------------------------------------------------------------------------------------------
 struct Job {
     Segment* seg;
@@ -314,58 +339,23 @@ struct Job {
     uint64_t mask_last;
 };
 
-// d_out[nq*k] / d_out_cnt[nq] are device buffers.  hq: host query words [nq][max_words].
-int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbytes, uint32_t k,
-                 isk::Record* d_out, uint32_t* d_out_cnt) {
-    const int tq = h->tq;
-    const uint32_t nq_pad = (nq + tq - 1) / tq * tq;
-    const uint32_t groups = nq_pad / tq;
-
+struct Batch {
+    H* h;
+    Table& t;
+    uint32_t nq, qbytes, k;
+    isk::Record* d_out;       // [nq*k]   device
+    uint32_t* d_out_cnt;      // [nq]     device
+    int tq = 8;
+    uint32_t nq_pad = 0, groups = 0, cap = 0, P = 0;
+    size_t sel_lds = 0;
+    bool multi = false;
     std::vector<Job> jobs;
-    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
-        Segment& s = t.seg[b];
-        if (!s.n) continue;
-        Job j;
-        j.seg = &s;
-        j.pbytes = t.metric == ISCCSEARCH_METRIC_NPHD ? std::min(b, qbytes) : b;
-        j.W = (j.pbytes + 7) / 8;
-        j.mask = (j.pbytes & 7) != 0;
-        j.mask_last = mask_for(j.pbytes);
-        jobs.push_back(j);
-    }
-    if (jobs.empty()) {
-        HIPOK(hipMemsetAsync(d_out_cnt, 0, nq * sizeof(uint32_t), h->stream));
-        return 0;
-    }
 
-    const uint32_t cap = std::max<uint32_t>(16384, 8 * k);
-    int rc;
-    if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;
-    if ((rc = h->d_bias.ensure(nq_pad))) return rc;
-    if ((rc = h->d_cnt.ensure((size_t)nq_pad * isk::CNT_STRIDE))) return rc;
-    if ((rc = h->d_ghist.ensure((size_t)nq_pad * isk::HB))) return rc;
-    if ((rc = h->d_overflow.ensure((size_t)nq_pad * 33))) return rc;
-    if ((rc = h->d_cand.ensure((size_t)nq_pad * cap))) return rc;
-    const bool multi = jobs.size() > 1;
-    if (multi) {
-        if ((rc = h->d_lists.ensure(jobs.size() * (size_t)nq * k))) return rc;
-        if ((rc = h->d_listcnt.ensure(jobs.size() * (size_t)nq))) return rc;
-    }
+    Batch(H* h_, Table& t_, uint32_t nq_, uint32_t qbytes_, uint32_t k_, isk::Record* out, uint32_t* out_cnt)
+        : h(h_), t(t_), nq(nq_), qbytes(qbytes_), k(k_), d_out(out), d_out_cnt(out_cnt) {}
 
-    // stage queries: [nq_pad][4], padded words zero
-    std::vector<uint64_t> stage((size_t)nq_pad * 4, 0);
-    for (uint32_t q = 0; q < nq; ++q)
-        for (int w = 0; w < t.max_words; ++w) stage[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
-    HIPOK(hipMemcpyAsync(h->d_queries.p, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPOK(hipStreamSynchronize(h->stream));   // `stage` is pageable host memory about to go out of scope
-    HIPOK(hipMemsetAsync(h->d_overflow.p, 0, (size_t)nq_pad * jobs.size() * sizeof(uint32_t), h->stream));
-
-    const uint32_t P = next_pow2(k);
-    const size_t sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
-
-    // per-job kernel arguments
     struct Ctx { isk::ScanParams sp; isk::SelectParams sl; };
-    auto make_ctx = [&](size_t ji) {
+    Ctx make_ctx(size_t ji) const {
         const Job& j = jobs[ji];
         Segment& s = *j.seg;
         Ctx c{};
@@ -380,125 +370,197 @@ int search_batch(H* h, Table& t, uint32_t nq, const uint64_t* hq, uint32_t qbyte
         c.sl.overflow = h->d_overflow.p + ji * (size_t)nq_pad;
         c.sl.k = k; c.sl.P = P; c.sl.prefix_bits = j.pbytes * 8; c.sl.q_base = 0;
         return c;
-    };
-    auto launch_select = [&](const isk::SelectParams& sl, uint32_t blocks) {
+    }
+    void launch_select(const isk::SelectParams& sl, uint32_t blocks) const {
         if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
         else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
-    };
-
-    // ---- every job, back to back on the stream, no host synchronisation ----
-    for (size_t ji = 0; ji < jobs.size(); ++ji) {
-        const Job& j = jobs[ji];
-        Segment& s = *j.seg;
-        Ctx c = make_ctx(ji);
-        isk::ScanParams& sp = c.sp;
-
-        // 1. bootstrap threshold from the first s0 rows
-        const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
-        isk::BootParams bp{};
-        for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
-        bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
-        hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
-
-        // 2. sample scans: tighten the threshold level by level.  A scan of S rows under the threshold of
-        //    a sample of S' rows meets ~4096*k/S' candidates per wave-tile (each costs a fraction of a
-        //    tile), so every level grows the sample 8x, and the last level stops where its own cost
-        //    balances the candidate handling it saves the full scan: S_last ~ sqrt(cost * 4096 * k * n).
-        const double balance = std::sqrt((double)h->sample_cost / 100.0 * 4096.0 * (double)k * (double)s.n);
-        const uint64_t s_last = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, (uint64_t)balance));
-        for (uint64_t sample = s0; sample < s_last;) {
-            sample = std::min<uint64_t>(s_last, sample * 8);
-            HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
-            sp.n_rows = sample;
-            launch_scan((int)j.W, j.mask, tq, isk::MODE_HIST, h->nontemporal, dim3(scan_grid_x(h, j.W, sample, groups, true), groups), h->stream, sp);
-            isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, sample)};
-            hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
-            h->stats.sample_bytes += sample * 8 * j.W * groups;
-        }
-
-        // 3. the streaming pass: collect every row within the threshold
-        HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
-        sp.n_rows = s.n;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
-        launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n, groups), groups), h->stream, sp);
-        if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
-        h->stats.scan_launches += 1;
-        h->stats.scan_passes += groups;
-        h->stats.scan_bytes += s.n * 8 * j.W * groups;
-
-        // 4. exact select of the k best candidates per query (flags candidate-list overflow)
-        launch_select(c.sl, nq);
-        HIPOK(hipGetLastError());
     }
+    size_t flag_words() const { return jobs.size() * (size_t)nq_pad; }
 
-    // ---- ONE overflow check for all jobs (a small copy; almost always all zero) ----
-    h->h_overflow.resize((size_t)jobs.size() * nq_pad);
-    HIPOK(hipMemcpyAsync(h->h_overflow.data(), h->d_overflow.p, h->h_overflow.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPOK(hipStreamSynchronize(h->stream));
-    for (size_t ji = 0; ji < jobs.size(); ++ji) {
-        const Job& j = jobs[ji];
-        Segment& s = *j.seg;
-        for (uint32_t q = 0; q < nq; ++q) {
-            if (!h->h_overflow[ji * nq_pad + q]) continue;
-            // exact fallback for this query on this segment: full histogram -> exact threshold ->
-            // collect into a buffer sized to the tie class -> select
+    // hq: host query words [nq][max_words]
+    int begin(const uint64_t* hq) {
+        tq = h->tq;
+        nq_pad = (nq + tq - 1) / tq * tq;
+        groups = nq_pad / tq;
+        for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
+            Segment& s = t.seg[b];
+            if (!s.n) continue;
+            Job j;
+            j.seg = &s;
+            j.pbytes = t.metric == ISCCSEARCH_METRIC_NPHD ? std::min(b, qbytes) : b;
+            j.W = (j.pbytes + 7) / 8;
+            j.mask = (j.pbytes & 7) != 0;
+            j.mask_last = mask_for(j.pbytes);
+            jobs.push_back(j);
+        }
+        if (jobs.empty()) {
+            HIPOK(hipMemsetAsync(d_out_cnt, 0, nq * sizeof(uint32_t), h->stream));
+            return 0;
+        }
+        cap = std::max<uint32_t>(16384, 8 * k);
+        multi = jobs.size() > 1;
+        P = next_pow2(k);
+        sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
+        int rc;
+        if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;
+        if ((rc = h->d_bias.ensure(nq_pad))) return rc;
+        if ((rc = h->d_cnt.ensure((size_t)nq_pad * isk::CNT_STRIDE))) return rc;
+        if ((rc = h->d_ghist.ensure((size_t)nq_pad * isk::HB))) return rc;
+        if ((rc = h->d_overflow.ensure(flag_words()))) return rc;
+        if ((rc = h->d_cand.ensure((size_t)nq_pad * cap))) return rc;
+        if (multi) {
+            if ((rc = h->d_lists.ensure(jobs.size() * (size_t)nq * k))) return rc;
+            if ((rc = h->d_listcnt.ensure(jobs.size() * (size_t)nq))) return rc;
+        }
+        // stage queries through pinned memory: [nq_pad][4], padded words zero
+        if ((rc = h->p_queries.ensure((size_t)nq_pad * 4))) return rc;
+        memset(h->p_queries.p, 0, (size_t)nq_pad * 4 * 8);
+        for (uint32_t q = 0; q < nq; ++q)
+            for (int w = 0; w < t.max_words; ++w) h->p_queries.p[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
+        HIPOK(hipMemcpyAsync(h->d_queries.p, h->p_queries.p, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPOK(hipMemsetAsync(h->d_overflow.p, 0, flag_words() * sizeof(uint32_t), h->stream));
+
+        for (size_t ji = 0; ji < jobs.size(); ++ji) {
+            const Job& j = jobs[ji];
+            Segment& s = *j.seg;
             Ctx c = make_ctx(ji);
-            h->stats.fallback_queries += 1;
-            if ((rc = h->d_misc.ensure(isk::HB + 8))) return rc;
-            uint32_t* d_fh = reinterpret_cast<uint32_t*>(h->d_misc.p);
-            HIPOK(hipMemsetAsync(d_fh, 0, isk::HB * sizeof(uint32_t), h->stream));
-            isk::FullHistParams fp{};
-            for (uint32_t w = 0; w < j.W; ++w) fp.col[w] = s.col[w];
-            fp.n_rows = s.n; fp.query = h->d_queries.p + (size_t)q * 4; fp.ghist = d_fh; fp.W = j.W; fp.mask_last = j.mask_last;
-            const uint32_t fgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + isk::BLOCK - 1) / isk::BLOCK, (uint64_t)h->cus * 8));
-            hipLaunchKernelGGL(isk::fullhist_kernel, dim3(fgrid), dim3(isk::BLOCK), 0, h->stream, fp);
-            uint32_t fh[isk::HB];
-            HIPOK(hipMemcpyAsync(fh, d_fh, sizeof fh, hipMemcpyDeviceToHost, h->stream));
-            HIPOK(hipStreamSynchronize(h->stream));
-            uint64_t cum = 0;
-            uint32_t tau = 256;
-            const uint64_t need = std::min<uint64_t>(k, s.n);
-            for (uint32_t b = 0; b < isk::NBINS; ++b) { cum += fh[b]; if (cum >= need) { tau = b; break; } }
-            // candidates with hamming <= tau: exactly `cum` rows, collected into a private buffer
-            if (cum > 0xFFFFFFFFull) return fail(-E2BIG, "tie class of %llu rows exceeds the fallback buffer", (unsigned long long)cum);
-            if ((rc = h->d_misc2.ensure((size_t)cum + 8))) return rc;
-            // rerun only the group holding q; every other slot of the group gets BIAS_NEVER
-            const uint32_t g = q / tq, ql = q - g * tq;
-            std::vector<uint32_t> hb(tq, isk::BIAS_NEVER);
-            hb[ql] = 0x7FFFFFFFu - tau;
-            HIPOK(hipMemcpyAsync(h->d_bias.p + (size_t)g * tq, hb.data(), tq * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-            HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE, 0, (size_t)tq * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
-            isk::ScanParams fsp = c.sp;
-            fsp.n_rows = s.n;
-            fsp.cap = (uint32_t)cum;
-            fsp.queries = h->d_queries.p + (size_t)g * tq * 4;
-            fsp.bias = h->d_bias.p + (size_t)g * tq;
-            fsp.cnt = h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE;
-            // slot ql of the group appends at cand[ql*cap + i]: bias the base so that lands at d_misc2[i]
-            fsp.cand = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)ql * fsp.cap * 8);
-            launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), 1), h->stream, fsp);
-            HIPOK(hipStreamSynchronize(h->stream));   // hb is pageable host memory
-            isk::SelectParams fsl = c.sl;
-            fsl.cnt = h->d_cnt.p; fsl.cap = fsp.cap; fsl.q_base = q;
-            fsl.cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)q * fsp.cap * 8);
-            // reset the overflow flag of q so a second overflow would be seen
-            HIPOK(hipMemsetAsync(c.sl.overflow + q, 0, sizeof(uint32_t), h->stream));
-            launch_select(fsl, 1);
+            isk::ScanParams& sp = c.sp;
+
+            // 1. bootstrap threshold from the first s0 rows
+            const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
+            isk::BootParams bp{};
+            for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
+            bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
+            hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
+
+            // 2. sample scans: tighten the threshold level by level.  A scan of S rows under the threshold
+            //    of a sample of S' rows meets ~4096*k/S' candidates per wave-tile (each costs a fraction of
+            //    a tile), so every level grows the sample (8x; 64x when there are so few query groups
+            //    that launch gaps outweigh candidate handling), and the last level stops where its own
+            //    cost balances the candidate handling it saves the full scan:
+            //    S_last ~ sqrt(cost * 4096 * k * n).
+            const double balance = std::sqrt((double)h->sample_cost / 100.0 * 4096.0 * (double)k * (double)s.n);
+            const uint64_t s_last = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, (uint64_t)balance));
+            const uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;
+            for (uint64_t sample = s0; sample < s_last;) {
+                sample = std::min<uint64_t>(s_last, sample * growth);
+                HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
+                sp.n_rows = sample;
+                launch_scan((int)j.W, j.mask, tq, isk::MODE_HIST, h->nontemporal, dim3(scan_grid_x(h, j.W, sample, groups, true), groups), h->stream, sp);
+                isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, sample)};
+                hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
+                h->stats.sample_bytes += sample * 8 * j.W * groups;
+            }
+
+            // 3. the streaming pass: collect every row within the threshold
+            HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
+            sp.n_rows = s.n;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
+            launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n, groups), groups), h->stream, sp);
+            if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+            h->stats.scan_launches += 1;
+            h->stats.scan_passes += groups;
+            h->stats.scan_bytes += s.n * 8 * j.W * groups;
+
+            // 4. exact select of the k best candidates per query (flags candidate-list overflow)
+            launch_select(c.sl, nq);
             HIPOK(hipGetLastError());
-            HIPOK(hipStreamSynchronize(h->stream));
         }
+        return 0;
     }
 
-    if (multi) {
+    // queue the overflow flags for the host (pinned); valid after the next stream synchronisation
+    int copy_flags() {
+        if (jobs.empty()) return 0;
+        int rc;
+        if ((rc = h->p_flags.ensure(flag_words()))) return rc;
+        HIPOK(hipMemcpyAsync(h->p_flags.p, h->d_overflow.p, flag_words() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        return 0;
+    }
+    bool any_flag() const {
+        for (size_t i = 0; i < flag_words(); ++i) if (h->p_flags.p[i]) return true;
+        return false;
+    }
+
+    // exact fallback for every flagged (job, query): full histogram -> exact threshold -> collect into
+    // a buffer sized to the tie class -> select.  Synchronous; rare.
+    int fix() {
+        int rc;
+        for (size_t ji = 0; ji < jobs.size(); ++ji) {
+            const Job& j = jobs[ji];
+            Segment& s = *j.seg;
+            for (uint32_t q = 0; q < nq; ++q) {
+                if (!h->p_flags.p[ji * nq_pad + q]) continue;
+                Ctx c = make_ctx(ji);
+                h->stats.fallback_queries += 1;
+                if ((rc = h->d_misc.ensure(isk::HB + 8))) return rc;
+                uint32_t* d_fh = reinterpret_cast<uint32_t*>(h->d_misc.p);
+                HIPOK(hipMemsetAsync(d_fh, 0, isk::HB * sizeof(uint32_t), h->stream));
+                isk::FullHistParams fp{};
+                for (uint32_t w = 0; w < j.W; ++w) fp.col[w] = s.col[w];
+                fp.n_rows = s.n; fp.query = h->d_queries.p + (size_t)q * 4; fp.ghist = d_fh; fp.W = j.W; fp.mask_last = j.mask_last;
+                const uint32_t fgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + isk::BLOCK - 1) / isk::BLOCK, (uint64_t)h->cus * 8));
+                hipLaunchKernelGGL(isk::fullhist_kernel, dim3(fgrid), dim3(isk::BLOCK), 0, h->stream, fp);
+                uint32_t fh[isk::HB];
+                HIPOK(hipMemcpyAsync(fh, d_fh, sizeof fh, hipMemcpyDeviceToHost, h->stream));
+                HIPOK(hipStreamSynchronize(h->stream));
+                uint64_t cum = 0;
+                uint32_t tau = 256;
+                const uint64_t need = std::min<uint64_t>(k, s.n);
+                for (uint32_t b = 0; b < isk::NBINS; ++b) { cum += fh[b]; if (cum >= need) { tau = b; break; } }
+                // candidates with hamming <= tau: exactly `cum` rows, collected into a private buffer
+                if (cum > 0xFFFFFFFFull) return fail(-E2BIG, "tie class of %llu rows exceeds the fallback buffer", (unsigned long long)cum);
+                if ((rc = h->d_misc2.ensure((size_t)cum + 8))) return rc;
+                // rerun only the group holding q; every other slot of the group gets BIAS_NEVER
+                const uint32_t g = q / tq, ql = q - g * tq;
+                std::vector<uint32_t> hb(tq, isk::BIAS_NEVER);
+                hb[ql] = 0x7FFFFFFFu - tau;
+                HIPOK(hipMemcpyAsync(h->d_bias.p + (size_t)g * tq, hb.data(), tq * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+                HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE, 0, (size_t)tq * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
+                isk::ScanParams fsp = c.sp;
+                fsp.n_rows = s.n;
+                fsp.cap = (uint32_t)cum;
+                fsp.queries = h->d_queries.p + (size_t)g * tq * 4;
+                fsp.bias = h->d_bias.p + (size_t)g * tq;
+                fsp.cnt = h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE;
+                // slot ql of the group appends at cand[ql*cap + i]: bias the base so that lands at d_misc2[i]
+                fsp.cand = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)ql * fsp.cap * 8);
+                launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), 1), h->stream, fsp);
+                HIPOK(hipStreamSynchronize(h->stream));   // hb is pageable host memory
+                isk::SelectParams fsl = c.sl;
+                fsl.cnt = h->d_cnt.p; fsl.cap = fsp.cap; fsl.q_base = q;
+                fsl.cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)q * fsp.cap * 8);
+                HIPOK(hipMemsetAsync(c.sl.overflow + q, 0, sizeof(uint32_t), h->stream));
+                launch_select(fsl, 1);
+                HIPOK(hipGetLastError());
+                HIPOK(hipStreamSynchronize(h->stream));
+            }
+        }
+        return 0;
+    }
+
+    int merge() {
+        if (!multi) return 0;
         isk::MergeParams mp{reinterpret_cast<const unsigned char*>(h->d_lists.p), reinterpret_cast<const unsigned char*>(h->d_listcnt.p),
                             (uint64_t)nq * k * sizeof(isk::Record), (uint64_t)nq * sizeof(uint32_t),
                             d_out, d_out_cnt, (uint32_t)jobs.size(), nq, k};
         hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
+        HIPOK(hipGetLastError());
+        return 0;
     }
-    HIPOK(hipGetLastError());
-    return 0;
-}
+
+    // everything up to final device-resident results (used by the device variant and multi-segment tables)
+    int run_to_device(const uint64_t* hq) {
+        int rc;
+        if ((rc = begin(hq))) return rc;
+        if (jobs.empty()) return 0;
+        if ((rc = copy_flags())) return rc;
+        HIPOK(hipStreamSynchronize(h->stream));
+        if (any_flag() && (rc = fix())) return rc;
+        return merge();
+    }
+};
 
 void unpack_records(const isk::Record* rec, const uint32_t* cnt, uint32_t nq, uint32_t k, int key_words,
                     const uint32_t* dest_index /*nullable: original query index per row*/,
@@ -588,6 +650,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         h->d_queries.release(); h->d_bias.release(); h->d_cnt.release(); h->d_ghist.release();
         h->d_overflow.release(); h->d_listcnt.release(); h->d_outcnt.release(); h->d_cand.release();
         h->d_lists.release(); h->d_final.release(); h->d_misc.release(); h->d_misc2.release();
+        h->p_queries.release(); h->p_flags.release(); h->p_cnt.release(); h->p_final.release();
         if (h->d_rank) (void)hipFree(h->d_rank);
         for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -951,13 +1014,35 @@ int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const u
             memcpy(&hq[(size_t)i * t.max_words], q_words + (size_t)order[pos + i] * t.max_words, (size_t)t.max_words * 8);
         if ((rc = h->d_final.ensure((size_t)m * k))) return rc;
         if ((rc = h->d_outcnt.ensure(m))) return rc;
-        if ((rc = search_batch(h, t, m, hq.data(), len, k, h->d_final.p, h->d_outcnt.p))) return rc;
-        h->h_final.resize((size_t)m * k);
-        h->h_cnt.resize(m);
-        HIPOK(hipMemcpyAsync(h->h_final.data(), h->d_final.p, (size_t)m * k * sizeof(isk::Record), hipMemcpyDeviceToHost, h->stream));
-        HIPOK(hipMemcpyAsync(h->h_cnt.data(), h->d_outcnt.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPOK(hipStreamSynchronize(h->stream));
-        unpack_records(h->h_final.data(), h->h_cnt.data(), m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
+        if ((rc = h->p_final.ensure((size_t)m * k))) return rc;
+        if ((rc = h->p_cnt.ensure(m))) return rc;
+        Batch batch(h, t, m, len, k, h->d_final.p, h->d_outcnt.p);
+        auto copy_results = [&]() -> int {
+            HIPOK(hipMemcpyAsync(h->p_final.p, h->d_final.p, (size_t)m * k * sizeof(isk::Record), hipMemcpyDeviceToHost, h->stream));
+            HIPOK(hipMemcpyAsync(h->p_cnt.p, h->d_outcnt.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            return 0;
+        };
+        if ((rc = batch.begin(hq.data()))) return rc;
+        if (batch.multi) {
+            // the per-segment lists must be complete before they are merged
+            if ((rc = batch.copy_flags())) return rc;
+            HIPOK(hipStreamSynchronize(h->stream));
+            if (batch.any_flag() && (rc = batch.fix())) return rc;
+            if ((rc = batch.merge())) return rc;
+            if ((rc = copy_results())) return rc;
+            HIPOK(hipStreamSynchronize(h->stream));
+        } else {
+            // one segment: flags and results travel together, ONE synchronisation per batch
+            if ((rc = batch.copy_flags())) return rc;
+            if ((rc = copy_results())) return rc;
+            HIPOK(hipStreamSynchronize(h->stream));
+            if (!batch.jobs.empty() && batch.any_flag()) {
+                if ((rc = batch.fix())) return rc;
+                if ((rc = copy_results())) return rc;
+                HIPOK(hipStreamSynchronize(h->stream));
+            }
+        }
+        unpack_records(h->p_final.p, h->p_cnt.p, m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
         pos = end;
     }
     return 0;
@@ -988,7 +1073,8 @@ int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, 
     isk::Record* out = static_cast<isk::Record*>(d_records);
     for (uint32_t pos = 0; pos < nq; pos += QB_MAX) {
         const uint32_t m = std::min<uint32_t>(QB_MAX, nq - pos);
-        if ((rc = search_batch(h, t, m, q_words + (size_t)pos * t.max_words, len, k, out + (size_t)pos * k, d_counts + pos))) return rc;
+        Batch batch(h, t, m, len, k, out + (size_t)pos * k, d_counts + pos);
+        if ((rc = batch.run_to_device(q_words + (size_t)pos * t.max_words))) return rc;
     }
     HIPOK(hipStreamSynchronize(h->stream));
     return 0;
