@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
+    ap.add_argument("--force-collective", action="store_true", help="initialise RCCL and run the all-gather even with one rank (rehearsal)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     args = ap.parse_args()
 
@@ -96,8 +97,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:   # only the one-rank rehearsal gets here without torchrun
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     words = (args.nbytes + 7) // 8
@@ -109,7 +118,7 @@ def main():
     table = engine.open_table(_lib.METRIC_HAMMING, 1, args.nbytes)
     lo, hi = shard_range(args.rows, rank, world)
     table.add_synthetic(args.nbytes, hi - lo, SEED_CODES, first_row=lo, key_base=0)
-    sharded = ShardedTable(HipShardOps(table, device))
+    sharded = ShardedTable(HipShardOps(table, device), always_gather=args.force_collective)
 
     q, planted = make_queries(args.queries, args.rows, words)
 
@@ -213,7 +222,7 @@ def main():
         print(json.dumps(out))
     table.drop()
     engine.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -77,12 +77,13 @@ class ShardedTable:
     Every rank calls ``search`` with the SAME queries and gets the SAME global top-k back.
     """
 
-    def __init__(self, ops, group=None):
+    def __init__(self, ops, group=None, always_gather=False):
         import torch.distributed as dist
 
         self.dist = dist
         self.ops = ops
         self.group = group
+        self.always_gather = always_gather   # run the collective even with one rank (rehearsal on one GPU)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -90,7 +91,7 @@ class ShardedTable:
         # type: (np.ndarray, np.ndarray | None, int) -> tuple
         nq = q_words.shape[0]
         block = self.ops.local_search(q_words, q_nbytes, k)
-        if self.world_size == 1:
+        if self.world_size == 1 and not (self.always_gather and self.dist.is_initialized()):
             return self.ops.merge(block, 1, nq, k)
         import torch
 
