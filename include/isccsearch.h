@@ -108,6 +108,18 @@ int isccsearch_contains(isccsearch_handle* h, uint32_t table, uint64_t n, const 
 int isccsearch_get(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
                    uint64_t* out_words, uint8_t* out_nbytes);
 
+/* Snapshot support (the reference's flush/close/rebuild of HNSW shard files has no equivalent: codes live
+ * in HBM; iscc_search/indexes/usearch/index.py:883-967).  Segments are addressed by code length in bytes.
+ *   segments:    out_rows[ISCCSEARCH_MAX_BYTES + 1], out_rows[b] = rows whose codes are b bytes long
+ *   export:      rows [first_row, first_row+n) of one segment: out_keys[n*key_words] and out_cols laid out
+ *                COLUMN-major [W][n] (W = ceil(nbytes/8)), i.e. exactly the device layout
+ *   add_columns: append n rows of one length from column-major words (no host transposition) */
+int isccsearch_segments(isccsearch_handle* h, uint32_t table, uint64_t* out_rows);
+int isccsearch_export(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t first_row, uint64_t n,
+                      uint64_t* out_keys, uint64_t* out_cols);
+int isccsearch_add_columns(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t n, const uint64_t* keys,
+                           const uint64_t* cols, uint32_t flags);
+
 /* Bench / test helper: append n rows generated ON THE DEVICE, nbytes long each:
  *   word w of row i = splitmix64(seed + 4*(first_row + i) + w),  key = key_base + first_row + i
  * (SURVEY.md section 8d synthetic generator).  Rows are not entered into the host key index. */

@@ -24,6 +24,7 @@ EXPORTS = (
     "isccsearch_create", "isccsearch_destroy", "isccsearch_last_error", "isccsearch_set_option",
     "isccsearch_stats_get", "isccsearch_table_open", "isccsearch_table_drop", "isccsearch_reserve",
     "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
+    "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
     "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_device", "isccsearch_merge_device",
 )
 
@@ -97,6 +98,9 @@ def load_library():
         "isccsearch_remove": (i, [vp, u32, u64, u64p, u64p]),
         "isccsearch_contains": (i, [vp, u32, u64, u64p, u8p]),
         "isccsearch_get": (i, [vp, u32, u64, u64p, u64p, u8p]),
+        "isccsearch_segments": (i, [vp, u32, u64p]),
+        "isccsearch_export": (i, [vp, u32, i, u64, u64, u64p, u64p]),
+        "isccsearch_add_columns": (i, [vp, u32, i, u64, u64p, u64p, u32]),
         "isccsearch_add_synthetic": (i, [vp, u32, i, u64, u64, u64, u64]),
         "isccsearch_search": (i, [vp, u32, u32, u64p, u8p, u32, u64p, u32p, u16p, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),

@@ -833,6 +833,80 @@ int isccsearch_add(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
     return 0;
 }
 
+int isccsearch_segments(isccsearch_handle* h, uint32_t table, uint64_t* out_rows) {
+    if (!h || !out_rows) return fail(-EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    out_rows[0] = 0;
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) out_rows[b] = tp->seg[b].n;
+    return 0;
+}
+
+int isccsearch_export(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t first_row, uint64_t n,
+                      uint64_t* out_keys, uint64_t* out_cols) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    if (!out_keys || !out_cols) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    if (nbytes < 1 || nbytes > tp->max_bytes) return fail(-EINVAL, "nbytes %d outside 1..%d", nbytes, tp->max_bytes);
+    Segment& s = tp->seg[nbytes];
+    if (first_row > s.n || n > s.n - first_row) return fail(-EINVAL, "rows [%llu, +%llu) outside the segment's %llu rows", (unsigned long long)first_row, (unsigned long long)n, (unsigned long long)s.n);
+    HIPOK(hipSetDevice(h->device));
+    for (uint32_t w = 0; w < s.W; ++w)
+        HIPOK(hipMemcpyAsync(out_cols + (size_t)w * n, s.col[w] + first_row, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipMemcpyAsync(out_keys, s.keys + first_row * tp->key_words, n * 8 * tp->key_words, hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int isccsearch_add_columns(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t n, const uint64_t* keys,
+                           const uint64_t* cols, uint32_t flags) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    if (!keys || !cols) return fail(-EINVAL, "keys/cols are NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    if (nbytes < 1 || nbytes > t.max_bytes) return fail(-EINVAL, "nbytes %d outside 1..%d", nbytes, t.max_bytes);
+    if (t.metric == ISCCSEARCH_METRIC_HAMMING && nbytes != t.max_bytes) return fail(-EINVAL, "Hamming tables hold %d-byte codes only", t.max_bytes);
+    HIPOK(hipSetDevice(h->device));
+    const int KW = t.key_words;
+    const bool trusted = (flags & ISCCSEARCH_ADD_TRUSTED_UNIQUE) != 0;
+    if (!trusted) {
+        if ((rc = ensure_index(h, t))) return rc;
+        std::unordered_map<Key, int, KeyHash> seen;
+        seen.reserve((size_t)n);
+        for (uint64_t i = 0; i < n; ++i) {
+            Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
+            if (t.index.count(k) || !seen.emplace(k, 1).second)
+                return fail(-EEXIST, "key %016llx%016llx already present (row %llu of the batch)", (unsigned long long)k.hi, (unsigned long long)k.lo, (unsigned long long)i);
+        }
+    }
+    Segment& s = t.seg[nbytes];
+    if ((rc = seg_reserve(h, t, s, s.n + n))) return rc;
+    for (uint32_t w = 0; w < s.W; ++w)
+        HIPOK(hipMemcpyAsync(s.col[w] + s.n, cols + (size_t)w * n, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPOK(hipMemcpyAsync(s.keys + s.n * KW, keys, n * 8 * KW, hipMemcpyHostToDevice, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    if (t.indexed) {
+        s.hkeys.insert(s.hkeys.end(), keys, keys + n * KW);
+        for (uint64_t r = 0; r < n; ++r) {
+            Key k = KW == 2 ? Key{keys[2 * r], keys[2 * r + 1]} : Key{0, keys[r]};
+            t.index[k] = Loc{(uint32_t)nbytes, s.n + r};
+        }
+    }
+    s.n += n;
+    t.total += n;
+    return 0;
+}
+
 int isccsearch_add_synthetic(isccsearch_handle* h, uint32_t table, int nbytes, uint64_t n,
                              uint64_t seed, uint64_t first_row, uint64_t key_base) {
     if (!h) return fail(-EINVAL, "handle is NULL");

@@ -273,6 +273,104 @@ class HipTable:
             )
         )
 
+    # -- snapshot (raw little-endian column files) --------------------------
+    def segments(self):
+        # type: () -> dict[int, int]
+        """{code length in bytes: rows} of the non-empty segments."""
+        out = np.zeros(_lib.MAX_BYTES + 1, dtype=np.uint64)
+        _lib.check(self.engine._lib.isccsearch_segments(self.engine.handle, self.id, _lib.ptr(out, ctypes.c_uint64)))
+        return {b: int(out[b]) for b in range(1, _lib.MAX_BYTES + 1) if out[b]}
+
+    def export_rows(self, nbytes, first_row, n):
+        # type: (int, int, int) -> tuple[np.ndarray, np.ndarray]
+        """(keys [n(,2)], cols [W, n]) of rows [first_row, first_row+n) of one segment, device layout."""
+        W = (nbytes + 7) // 8
+        keys = np.zeros((n, 2) if self.key_words == 2 else n, dtype=np.uint64)
+        cols = np.zeros((W, n), dtype=np.uint64)
+        if n:
+            _lib.check(
+                self.engine._lib.isccsearch_export(
+                    self.engine.handle, self.id, nbytes, first_row, n, _lib.ptr(keys, ctypes.c_uint64), _lib.ptr(cols, ctypes.c_uint64)
+                )
+            )
+        return keys, cols
+
+    def add_columns(self, nbytes, keys, cols, trusted_unique=False):
+        # type: (int, np.ndarray, np.ndarray, bool) -> None
+        keys = self._keys(keys)
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        n = keys.shape[0]
+        if cols.shape != ((nbytes + 7) // 8, n):
+            raise ValueError(f"cols must be shaped [{(nbytes + 7) // 8}, {n}]")
+        if n:
+            _lib.check(
+                self.engine._lib.isccsearch_add_columns(
+                    self.engine.handle, self.id, nbytes, n, _lib.ptr(keys, ctypes.c_uint64), _lib.ptr(cols, ctypes.c_uint64),
+                    _lib.ADD_TRUSTED_UNIQUE if trusted_unique else 0,
+                )
+            )
+
+    def save(self, path, chunk_rows=1 << 24):
+        # type: (str, int) -> None
+        """
+        Write the table as raw little-endian files: ``table.json`` + per segment ``segNN.keys.u64`` and
+        ``segNN.wI.u64`` (one file per 64-bit word column, the device layout), streamed in chunks.
+        """
+        import json
+        import os
+
+        os.makedirs(path, exist_ok=True)
+        segs = self.segments()
+        for nbytes, rows in segs.items():
+            W = (nbytes + 7) // 8
+            files = [open(os.path.join(path, f"seg{nbytes:02d}.w{w}.u64.tmp"), "wb") for w in range(W)]
+            kf = open(os.path.join(path, f"seg{nbytes:02d}.keys.u64.tmp"), "wb")
+            try:
+                for first in range(0, rows, chunk_rows):
+                    n = min(chunk_rows, rows - first)
+                    keys, cols = self.export_rows(nbytes, first, n)
+                    keys.astype("<u8", copy=False).tofile(kf)
+                    for w in range(W):
+                        cols[w].astype("<u8", copy=False).tofile(files[w])
+            finally:
+                kf.close()
+                for f in files:
+                    f.close()
+            for w in range(W):
+                os.replace(os.path.join(path, f"seg{nbytes:02d}.w{w}.u64.tmp"), os.path.join(path, f"seg{nbytes:02d}.w{w}.u64"))
+            os.replace(os.path.join(path, f"seg{nbytes:02d}.keys.u64.tmp"), os.path.join(path, f"seg{nbytes:02d}.keys.u64"))
+        meta = {"format": 1, "metric": self.metric, "key_words": self.key_words, "max_bytes": self.max_bytes,
+                "segments": {str(b): r for b, r in segs.items()}}
+        with open(os.path.join(path, "table.json.tmp"), "w") as f:
+            json.dump(meta, f)
+        os.replace(os.path.join(path, "table.json.tmp"), os.path.join(path, "table.json"))
+
+    def load(self, path, chunk_rows=1 << 24):
+        # type: (str, int) -> None
+        """Append the rows of a snapshot written by ``save`` (memory-mapped, streamed host -> device)."""
+        import json
+        import os
+
+        with open(os.path.join(path, "table.json")) as f:
+            meta = json.load(f)
+        if (meta["metric"], meta["key_words"], meta["max_bytes"]) != (self.metric, self.key_words, self.max_bytes):
+            raise ValueError(f"snapshot at {path} does not match this table's metric / key width / code length")
+        for b_str, rows in meta["segments"].items():
+            nbytes, rows = int(b_str), int(rows)
+            W = (nbytes + 7) // 8
+            kmap = np.memmap(os.path.join(path, f"seg{nbytes:02d}.keys.u64"), dtype="<u8", mode="r")
+            cmaps = [np.memmap(os.path.join(path, f"seg{nbytes:02d}.w{w}.u64"), dtype="<u8", mode="r") for w in range(W)]
+            if kmap.shape[0] != rows * self.key_words or any(c.shape[0] != rows for c in cmaps):
+                raise ValueError(f"snapshot at {path}: segment {nbytes} is truncated")
+            self.reserve(nbytes, self.segments().get(nbytes, 0) + rows)
+            for first in range(0, rows, chunk_rows):
+                n = min(chunk_rows, rows - first)
+                keys = np.array(kmap[first * self.key_words : (first + n) * self.key_words], dtype=np.uint64)
+                if self.key_words == 2:
+                    keys = keys.reshape(n, 2)
+                cols = np.stack([np.asarray(c[first : first + n], dtype=np.uint64) for c in cmaps])
+                self.add_columns(nbytes, keys, cols, trusted_unique=True)
+
     def drop(self):
         # type: () -> None
         if self._open and self.engine._h is not None:

@@ -12,7 +12,10 @@ search is the exact GPU scan.  Scoring, thresholds, aggregation, self-exclusion,
 messages follow ``index.py:735-881`` and ``:1357-1469``.
 """
 
+import json
+import os
 import re
+import shutil
 import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -88,6 +91,7 @@ class HipIndex:
         self._sp_tables = {}  # type: Dict[str, HipSimprintIndex]
         self._sp_assets = {}  # type: Dict[str, Dict[bytes, list]]   sp_type -> body -> [(sp_bytes, chunk_ptr)]
         self._sp_freq = {}  # type: Dict[str, Dict[bytes, Dict[bytes, int]]]  sp_type -> sp_bytes -> {body: n}
+        self.dirty = False
 
     # -- helpers ---------------------------------------------------------------------------------
     def __len__(self):
@@ -207,6 +211,8 @@ class HipIndex:
                 if sp_type in sp_deleted:
                     table.remove(sp_deleted[sp_type])
                 table.add_raw(ckeys, vecs)
+            if staged:
+                self.dirty = True
             return results
 
     def _fingerprint_of(self, sp_type, body):
@@ -353,6 +359,66 @@ class HipIndex:
             out.append(IsccChunkMatch(iscc_id="ISCC:" + codec.encode_base32(digest), score=score, types=types, source=source, metadata=metadata))
         return out
 
+    # -- snapshot ------------------------------------------------------------------------------------
+    # The reference persists through LMDB + HNSW shard files and `flush()` / `close()`
+    # (usearch/index.py:883-967).  Here a snapshot is: index.json, assets.jsonl, and the raw code columns
+    # of every table (units/<type>/, simprints/<type>/) exactly as they sit in HBM.
+    def save(self, path):
+        # type: (str) -> None
+        with self._lock:
+            os.makedirs(path, exist_ok=True)
+            with open(os.path.join(path, "assets.jsonl.tmp"), "w") as f:
+                for key, asset in self._assets.items():
+                    f.write(json.dumps({"key": key, "asset": asset.model_dump(mode="json", exclude_none=True)}, separators=(",", ":")) + "\n")
+            os.replace(os.path.join(path, "assets.jsonl.tmp"), os.path.join(path, "assets.jsonl"))
+            for unit_type, table in self._unit_tables.items():
+                table.save(os.path.join(path, "units", unit_type))
+            for sp_type, table in self._sp_tables.items():
+                table.save(os.path.join(path, "simprints", sp_type))
+            meta = {
+                "format": 1, "realm_id": self._realm_id, "assets": len(self._assets),
+                "unit_types": sorted(self._unit_tables),
+                "simprint_types": {t: tbl.ndim for t, tbl in self._sp_tables.items()},
+            }
+            with open(os.path.join(path, "index.json.tmp"), "w") as f:
+                json.dump(meta, f)
+            os.replace(os.path.join(path, "index.json.tmp"), os.path.join(path, "index.json"))
+            self.dirty = False
+
+    @classmethod
+    def load(cls, engine, path, options=None):
+        # type: (object, str, HipOptions | None) -> HipIndex
+        from iscc_search_amd.simprint import unpack_chunk_pointer
+
+        with open(os.path.join(path, "index.json")) as f:
+            meta = json.load(f)
+        idx = cls(engine, options)
+        idx._realm_id = meta["realm_id"]
+        assets_file = os.path.join(path, "assets.jsonl")
+        if os.path.exists(assets_file):
+            with open(assets_file) as f:
+                for line in f:
+                    rec = json.loads(line)
+                    asset = IsccEntry(**rec["asset"])
+                    idx._assets[rec["key"]] = asset
+                    units = {}
+                    for unit_str in asset.units or []:
+                        u = codec.Iscc(unit_str)
+                        units[u.unit_type] = u.body
+                    idx._asset_units[rec["key"]] = units
+        for unit_type in meta["unit_types"]:
+            idx._unit_table(unit_type).load(os.path.join(path, "units", unit_type))
+        for sp_type, ndim in meta["simprint_types"].items():
+            table = idx._sp_table(sp_type, ndim)
+            table.load(os.path.join(path, "simprints", sp_type))
+            # host-side maps (per-asset chunk lists, document frequencies) are derived from the stored rows
+            for ckey, sp_bytes in table.rows():
+                body = unpack_chunk_pointer(ckey)[0]
+                idx._sp_assets[sp_type].setdefault(body, []).append((sp_bytes, ckey))
+                owners = idx._sp_freq[sp_type].setdefault(sp_bytes, {})
+                owners[body] = owners.get(body, 0) + 1
+        return idx
+
     def close(self):
         # type: () -> None
         with self._lock:
@@ -380,12 +446,21 @@ class HipIndexManager:
             raise ValueError(f"HipIndexManager requires a hip:// URI, got '{uri}'")
         qs = parse_qs(parsed.query)
         self.device_id = int(qs.get("device", ["0"])[0])
+        # hip:///            -> volatile (like memory://)
+        # hip:///abs/path    -> snapshots under that directory: loaded lazily, written by flush()/close()
+        self.base_path = parsed.path if parsed.path not in ("", "/") else None
         self._engine = engine
         self._owns_engine = engine is None
         self._opts = options or HipOptions()
         self._indexes = {}  # type: Dict[str, HipIndex]
+        self._on_disk = set()
         self._lock = threading.RLock()
         self._closed = False
+        if self.base_path:
+            os.makedirs(self.base_path, exist_ok=True)
+            for name in sorted(os.listdir(self.base_path)):
+                if INDEX_NAME_RE.match(name) and os.path.exists(os.path.join(self.base_path, name, "index.json")):
+                    self._on_disk.add(name)
 
     def _get_engine(self):
         if self._engine is None:
@@ -397,21 +472,43 @@ class HipIndexManager:
     def _index(self, name):
         # type: (str) -> HipIndex
         idx = self._indexes.get(name)
+        if idx is None and name in self._on_disk:
+            idx = self._indexes[name] = HipIndex.load(self._get_engine(), os.path.join(self.base_path, name), self._opts)
         if idx is None:
             raise FileNotFoundError(f"Index '{name}' not found")
         return idx
+
+    def _names(self):
+        return sorted(set(self._indexes) | self._on_disk)
+
+    def _asset_count(self, name):
+        if name in self._indexes:
+            return len(self._indexes[name])
+        with open(os.path.join(self.base_path, name, "index.json")) as f:
+            return json.load(f).get("assets", 0)
+
+    def flush(self):
+        # type: () -> None
+        """Write every modified index to its snapshot directory (no-op for volatile managers)."""
+        if not self.base_path:
+            return
+        with self._lock:
+            for name, idx in self._indexes.items():
+                if idx.dirty or name not in self._on_disk:
+                    idx.save(os.path.join(self.base_path, name))
+                    self._on_disk.add(name)
 
     # -- protocol ----------------------------------------------------------------------------------
     def list_indexes(self):
         # type: () -> List[IsccIndex]
         with self._lock:
-            return [IsccIndex(name=n, assets=len(i), size=0) for n, i in self._indexes.items()]
+            return [IsccIndex(name=n, assets=self._asset_count(n), size=0) for n in self._names()]
 
     def create_index(self, index):
         # type: (IsccIndex) -> IsccIndex
         validate_index_name(index.name)
         with self._lock:
-            if index.name in self._indexes:
+            if index.name in self._indexes or index.name in self._on_disk:
                 raise FileExistsError(f"Index '{index.name}' already exists")
             self._indexes[index.name] = HipIndex(self._get_engine(), self._opts)
         return IsccIndex(name=index.name, assets=0, size=0)
@@ -419,13 +516,20 @@ class HipIndexManager:
     def get_index(self, name):
         # type: (str) -> IsccIndex
         with self._lock:
-            return IsccIndex(name=name, assets=len(self._index(name)), size=0)
+            if name not in self._indexes and name not in self._on_disk:
+                raise FileNotFoundError(f"Index '{name}' not found")
+            return IsccIndex(name=name, assets=self._asset_count(name), size=0)
 
     def delete_index(self, name):
         # type: (str) -> None
         with self._lock:
-            self._index(name).close()
-            del self._indexes[name]
+            if name not in self._indexes and name not in self._on_disk:
+                raise FileNotFoundError(f"Index '{name}' not found")
+            if name in self._indexes:
+                self._indexes.pop(name).close()
+            if name in self._on_disk:
+                shutil.rmtree(os.path.join(self.base_path, name), ignore_errors=True)
+                self._on_disk.discard(name)
 
     def add_assets(self, index_name, assets):
         # type: (str, List[IsccEntry]) -> List[IsccAddResult]
@@ -457,6 +561,7 @@ class HipIndexManager:
             if self._closed:
                 return
             self._closed = True
+            self.flush()
             for idx in self._indexes.values():
                 idx.close()
             self._indexes.clear()

@@ -135,7 +135,15 @@ class HipNphdIndex:
             out.append(Matches(keys[q, :c].copy(), dist, ham[q, :c].copy(), pbits[q, :c].copy()))
         return out[0] if single else BatchMatches(out)
 
-    # -- lifecycle (persistence of the reference's shard files has no equivalent: data lives in HBM)
+    # -- lifecycle: the reference persists HNSW shard files (save/load); here a snapshot is the raw columns
+    def save(self, path):
+        # type: (str) -> None
+        self._table.save(path)
+
+    def load(self, path):
+        # type: (str) -> None
+        self._table.load(path)
+
     def reset(self):
         self._table.drop()
 
@@ -233,6 +241,26 @@ class HipIndex128:
             c = int(cnt[q])
             out.append(Matches(words_to_key128(keys[q, :c]), ham[q, :c].astype(np.float32), ham[q, :c].copy(), pbits[q, :c].copy()))
         return out[0] if single else BatchMatches(out)
+
+    def save(self, path):
+        # type: (str) -> None
+        self._table.save(path)
+
+    def load(self, path):
+        # type: (str) -> None
+        self._table.load(path)
+
+    def rows(self, chunk_rows=1 << 20):
+        """Iterate (key bytes, vector bytes) over every stored row (snapshot restore of host-side maps)."""
+        for nbytes, total in self._table.segments().items():
+            for first in range(0, total, chunk_rows):
+                n = min(chunk_rows, total - first)
+                keys, cols = self._table.export_rows(nbytes, first, n)
+                kb = words_to_key128(keys)
+                raw = np.ascontiguousarray(cols.T).astype(">u8").tobytes()
+                stride = cols.shape[0] * 8
+                for i in range(n):
+                    yield kb[i], raw[i * stride : i * stride + nbytes]
 
     def reset(self):
         self._table.drop()

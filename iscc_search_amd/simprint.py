@@ -171,6 +171,18 @@ class HipSimprintIndex:
         results.sort(key=lambda r: (-r.score, r.iscc_id_body))
         return results[:limit]
 
+    def save(self, path):
+        # type: (str) -> None
+        self._index.save(path)
+
+    def load(self, path):
+        # type: (str) -> None
+        self._index.load(path)
+
+    def rows(self):
+        """(composite key, simprint bytes) of every stored chunk."""
+        return self._index.rows()
+
     def reset(self):
         self._index.reset()
 

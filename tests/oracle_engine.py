@@ -119,8 +119,48 @@ class OracleTable:
                 rec[q, i]["dist_rank"] = ranks[(p // 8, h)] if self.metric == 1 else h
         return rec, cnt.astype(np.int32)
 
+    # snapshot interface (same duck type as HipTable; the file logic itself is the product's)
+    def segments(self):
+        out = {}
+        for _, (_, b) in self._rows.items():
+            out[b] = out.get(b, 0) + 1
+        return dict(sorted(out.items()))
+
+    def _seg_items(self, nbytes):
+        return [(k, w) for k, (w, b) in self._rows.items() if b == nbytes]
+
+    def export_rows(self, nbytes, first_row, n):
+        items = self._seg_items(nbytes)[first_row : first_row + n]
+        W = (nbytes + 7) // 8
+        keys = np.zeros((n, 2) if self.key_words == 2 else n, dtype=np.uint64)
+        cols = np.zeros((W, n), dtype=np.uint64)
+        for i, (k, w) in enumerate(items):
+            keys[i] = k if self.key_words == 2 else k[0]
+            cols[:, i] = w[:W]
+        return keys, cols
+
+    def add_columns(self, nbytes, keys, cols, trusted_unique=False):
+        keys = np.asarray(keys, dtype=np.uint64)
+        n = keys.shape[0]
+        words = np.zeros((n, self.max_words), dtype=np.uint64)
+        words[:, : cols.shape[0]] = np.asarray(cols, dtype=np.uint64).T
+        self.add(keys, words, np.full(n, nbytes, dtype=np.uint8) if self.metric == 1 else None, trusted_unique=trusted_unique)
+
+    def reserve(self, nbytes, rows):
+        pass
+
     def drop(self):
         self._rows.clear()
+
+
+def _borrow_snapshot_io():
+    from iscc_search_amd.engine import HipTable
+
+    OracleTable.save = HipTable.save
+    OracleTable.load = HipTable.load
+
+
+_borrow_snapshot_io()
 
 
 class OracleEngine:
