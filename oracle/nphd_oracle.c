@@ -87,30 +87,52 @@ static void heap_sift_up(hit_t* hp, size_t i) {
 }
 static int hit_qsort_cmp(const void* a, const void* b) { return hit_cmp((const hit_t*)a, (const hit_t*)b); }
 
-static void topk_one(int nphd, int key_words, int max_words, uint32_t fixed_nbytes,
-                     uint64_t n, const uint64_t* keys, const uint64_t* words, const uint8_t* nbytes,
-                     const uint64_t* q, uint32_t qbytes, uint32_t k,
-                     uint64_t row_lo, uint64_t row_hi, hit_t* heap, uint32_t* heap_n) {
-    (void)n;
-    uint32_t cnt = *heap_n;
-    for (uint64_t r = row_lo; r < row_hi; ++r) {
-        uint32_t rb = nbytes ? nbytes[r] : (fixed_nbytes ? fixed_nbytes : (uint32_t)max_words * 8);
-        uint32_t pb = nphd ? (rb < qbytes ? rb : qbytes) : rb;
-        hit_t c;
-        c.h = prefix_hamming(words + r * (uint64_t)max_words, q, pb);
-        c.p = nphd ? pb * 8 : 1;     /* hamming tables order by the raw bit count */
-        c.khi = key_words == 2 ? keys[2 * r] : 0;
-        c.klo = key_words == 2 ? keys[2 * r + 1] : keys[r];
-        if (cnt < k) {
-            heap[cnt] = c;
-            heap_sift_up(heap, cnt);
-            ++cnt;
-        } else if (hit_cmp(&c, &heap[0]) < 0) {
-            heap[0] = c;
-            heap_sift_down(heap, cnt, 0);
-        }
+/* distances of one tile of fixed-length rows (whole words) to one query; the compiler vectorises this loop */
+#define TILE_ROWS 2048
+#define TILE_BODY                                                                                        \
+    if (W == 1) {                                                                                        \
+        const uint64_t q0 = q[0];                                                                        \
+        for (uint32_t i = 0; i < n; ++i) out[i] = (uint32_t)__builtin_popcountll(rows[i] ^ q0);          \
+    } else if (W == 2) {                                                                                 \
+        const uint64_t q0 = q[0], q1 = q[1];                                                             \
+        for (uint32_t i = 0; i < n; ++i)                                                                 \
+            out[i] = (uint32_t)(__builtin_popcountll(rows[2 * i] ^ q0) + __builtin_popcountll(rows[2 * i + 1] ^ q1)); \
+    } else {                                                                                             \
+        for (uint32_t i = 0; i < n; ++i) {                                                               \
+            uint32_t h = 0;                                                                              \
+            for (int w = 0; w < W; ++w) h += (uint32_t)__builtin_popcountll(rows[(uint64_t)i * W + w] ^ q[w]); \
+            out[i] = h;                                                                                  \
+        }                                                                                                \
     }
-    *heap_n = cnt;
+static void tile_hamming_base(const uint64_t* rows, int W, const uint64_t* q, uint32_t n, uint32_t* out) { TILE_BODY }
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target("avx512f,avx512vl,avx512bw,avx512vpopcntdq")))
+static void tile_hamming_vpopcnt(const uint64_t* rows, int W, const uint64_t* q, uint32_t n, uint32_t* out) { TILE_BODY }
+static int have_vpopcnt(void) {
+    static int cached = -1;
+    if (cached < 0) cached = __builtin_cpu_supports("avx512vpopcntdq") && __builtin_cpu_supports("avx512vl") ? 1 : 0;
+    return cached;
+}
+#else
+static int have_vpopcnt(void) { return 0; }
+#define tile_hamming_vpopcnt tile_hamming_base
+#endif
+/* run-time dispatch: AVX-512 VPOPCNTQ where the host has it, plain popcnt elsewhere */
+static inline void tile_hamming(const uint64_t* rows, int W, const uint64_t* q, uint32_t n, uint32_t* out) {
+    if (have_vpopcnt()) tile_hamming_vpopcnt(rows, W, q, n, out);
+    else tile_hamming_base(rows, W, q, n, out);
+}
+int oracle_uses_vpopcnt(void) { return have_vpopcnt(); }
+
+static inline void heap_offer(hit_t* heap, uint32_t* cnt, uint32_t k, const hit_t* c) {
+    if (*cnt < k) {
+        heap[*cnt] = *c;
+        heap_sift_up(heap, *cnt);
+        ++*cnt;
+    } else if (hit_cmp(c, &heap[0]) < 0) {
+        heap[0] = *c;
+        heap_sift_down(heap, *cnt, 0);
+    }
 }
 
 /*
@@ -119,6 +141,10 @@ static void topk_one(int nphd, int key_words, int max_words, uint32_t fixed_nbyt
  * out_prefix_bits[nq*k] (the p the distance is normalised by; for metric 0 the table's
  * bit length), out_count[nq] = min(k, n).  Returns 0, or -1 on bad arguments.
  * threads <= 0 uses every core OpenMP sees.
+ *
+ * Parallelisation: the rows are split across threads; every thread walks its rows in cache-sized
+ * tiles and scores each tile against ALL queries (a tile is read from DRAM once), keeping one
+ * k-heap per query; the per-thread heaps are merged at the end.
  */
 int oracle_topk(int metric, int key_words, int max_words, uint32_t fixed_nbytes,
                 uint64_t n, const uint64_t* keys, const uint64_t* code_words, const uint8_t* nbytes,
@@ -126,66 +152,98 @@ int oracle_topk(int metric, int key_words, int max_words, uint32_t fixed_nbytes,
                 uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits,
                 uint32_t* out_count, int threads) {
     if (k < 1 || max_words < 1 || max_words > 4 || (key_words != 1 && key_words != 2)) return -1;
+    int nt = 1;
 #ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(threads);
+    nt = threads > 0 ? threads : omp_get_max_threads();
 #else
     (void)threads;
 #endif
-    int failed = 0;
-    /* Few queries over many rows: split the rows; many queries: split the queries. */
-    if (nq >= 8 || n < (1u << 16)) {
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int64_t qi = 0; qi < (int64_t)nq; ++qi) {
-            hit_t* heap = (hit_t*)malloc(sizeof(hit_t) * (size_t)k);
-            if (!heap) { failed = 1; continue; }
-            uint32_t cnt = 0;
-            uint32_t qb = q_nbytes ? q_nbytes[qi] : (fixed_nbytes ? fixed_nbytes : (uint32_t)max_words * 8);
-            topk_one(metric, key_words, max_words, fixed_nbytes, n, keys, code_words, nbytes,
-                     q_words + (uint64_t)qi * max_words, qb, k, 0, n, heap, &cnt);
-            qsort(heap, cnt, sizeof(hit_t), hit_qsort_cmp);
-            for (uint32_t i = 0; i < cnt; ++i) {
-                uint64_t o = (uint64_t)qi * k + i;
-                if (key_words == 2) { out_keys[2 * o] = heap[i].khi; out_keys[2 * o + 1] = heap[i].klo; }
-                else out_keys[o] = heap[i].klo;
-                out_hamming[o] = heap[i].h;
-                out_prefix_bits[o] = (uint16_t)(metric ? heap[i].p : (fixed_nbytes ? fixed_nbytes * 8 : (uint32_t)max_words * 64));
-            }
-            out_count[qi] = cnt;
-            free(heap);
-        }
-    } else {
-        int nt = 1;
+    if (nq == 0) return 0;
+    /* keep the per-thread heaps within ~256 MB */
+    while (nt > 1 && (uint64_t)nt * nq * k * sizeof(hit_t) > (256ull << 20)) nt /= 2;
+    if ((uint64_t)nt > n / TILE_ROWS + 1) nt = (int)(n / TILE_ROWS + 1);
+    hit_t* heaps = (hit_t*)malloc(sizeof(hit_t) * (size_t)k * nq * (size_t)nt);
+    uint32_t* cnts = (uint32_t*)calloc((size_t)nq * (size_t)nt, sizeof(uint32_t));
+    if (!heaps || !cnts) { free(heaps); free(cnts); return -1; }
+    const uint32_t table_bytes = fixed_nbytes ? fixed_nbytes : (uint32_t)max_words * 8;
+    /* fast path: fixed-length rows made of whole words */
+    const int whole_words = (!nbytes) && (table_bytes % 8 == 0) && (!metric || !q_nbytes);
+    const int W = (int)(table_bytes / 8);
+
+#pragma omp parallel num_threads(nt)
+    {
+        int tid = 0;
 #ifdef _OPENMP
-        nt = omp_get_max_threads();
+        tid = omp_get_thread_num();
 #endif
-        hit_t* heaps = (hit_t*)malloc(sizeof(hit_t) * (size_t)k * (size_t)nt);
-        uint32_t* cnts = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)nt);
-        hit_t* all = (hit_t*)malloc(sizeof(hit_t) * (size_t)k * (size_t)nt);
-        if (!heaps || !cnts || !all) { free(heaps); free(cnts); free(all); return -1; }
-        for (uint32_t qi = 0; qi < nq; ++qi) {
-            uint32_t qb = q_nbytes ? q_nbytes[qi] : (fixed_nbytes ? fixed_nbytes : (uint32_t)max_words * 8);
-            memset(cnts, 0, sizeof(uint32_t) * (size_t)nt);
-#pragma omp parallel for schedule(static, 1)
-            for (int t = 0; t < nt; ++t) {
-                uint64_t lo = n * (uint64_t)t / nt, hi = n * (uint64_t)(t + 1) / nt;
-                topk_one(metric, key_words, max_words, fixed_nbytes, n, keys, code_words, nbytes,
-                         q_words + (uint64_t)qi * max_words, qb, k, lo, hi, heaps + (size_t)t * k, &cnts[t]);
+        const uint64_t lo = n * (uint64_t)tid / (uint64_t)nt, hi = n * (uint64_t)(tid + 1) / (uint64_t)nt;
+        hit_t* my = heaps + (size_t)tid * nq * k;
+        uint32_t* mycnt = cnts + (size_t)tid * nq;
+        uint32_t dist[TILE_ROWS];
+        for (uint64_t t0 = lo; t0 < hi; t0 += TILE_ROWS) {
+            const uint32_t m = (uint32_t)((hi - t0) < TILE_ROWS ? (hi - t0) : TILE_ROWS);
+            for (uint32_t qi = 0; qi < nq; ++qi) {
+                hit_t* heap = my + (size_t)qi * k;
+                uint32_t* cnt = &mycnt[qi];
+                const uint64_t* q = q_words + (uint64_t)qi * max_words;
+                if (whole_words && W == max_words) {
+                    tile_hamming(code_words + t0 * (uint64_t)max_words, W, q, m, dist);
+                    for (uint32_t i = 0; i < m; ++i) {
+                        /* cheap reject: strictly worse than the worst kept hit */
+                        if (*cnt == k && dist[i] > heap[0].h) continue;
+                        hit_t c;
+                        c.h = dist[i];
+                        c.p = metric ? table_bytes * 8 : 1;
+                        c.khi = key_words == 2 ? keys[2 * (t0 + i)] : 0;
+                        c.klo = key_words == 2 ? keys[2 * (t0 + i) + 1] : keys[t0 + i];
+                        heap_offer(heap, cnt, k, &c);
+                    }
+                } else {
+                    const uint32_t qb = q_nbytes ? q_nbytes[qi] : table_bytes;
+                    for (uint32_t i = 0; i < m; ++i) {
+                        const uint64_t r = t0 + i;
+                        const uint32_t rb = nbytes ? nbytes[r] : table_bytes;
+                        const uint32_t pb = metric ? (rb < qb ? rb : qb) : rb;
+                        hit_t c;
+                        c.h = prefix_hamming(code_words + r * (uint64_t)max_words, q, pb);
+                        c.p = metric ? pb * 8 : 1;
+                        c.khi = key_words == 2 ? keys[2 * r] : 0;
+                        c.klo = key_words == 2 ? keys[2 * r + 1] : keys[r];
+                        heap_offer(heap, cnt, k, &c);
+                    }
+                }
             }
-            size_t m = 0;
-            for (int t = 0; t < nt; ++t) { memcpy(all + m, heaps + (size_t)t * k, sizeof(hit_t) * cnts[t]); m += cnts[t]; }
-            qsort(all, m, sizeof(hit_t), hit_qsort_cmp);
-            uint32_t cnt = m < k ? (uint32_t)m : k;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                uint64_t o = (uint64_t)qi * k + i;
-                if (key_words == 2) { out_keys[2 * o] = all[i].khi; out_keys[2 * o + 1] = all[i].klo; }
-                else out_keys[o] = all[i].klo;
-                out_hamming[o] = all[i].h;
-                out_prefix_bits[o] = (uint16_t)(metric ? all[i].p : (fixed_nbytes ? fixed_nbytes * 8 : (uint32_t)max_words * 64));
-            }
-            out_count[qi] = cnt;
         }
-        free(heaps); free(cnts); free(all);
     }
+
+    /* merge the per-thread heaps */
+    int failed = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt)
+    for (int64_t qi = 0; qi < (int64_t)nq; ++qi) {
+        size_t total = 0;
+        for (int t = 0; t < nt; ++t) total += cnts[(size_t)t * nq + qi];
+        hit_t* all = (hit_t*)malloc(sizeof(hit_t) * (total ? total : 1));
+        if (!all) { failed = 1; continue; }
+        size_t m = 0;
+        for (int t = 0; t < nt; ++t) {
+            const uint32_t c = cnts[(size_t)t * nq + qi];
+            memcpy(all + m, heaps + ((size_t)t * nq + qi) * k, sizeof(hit_t) * c);
+            m += c;
+        }
+        qsort(all, m, sizeof(hit_t), hit_qsort_cmp);
+        const uint32_t cnt = m < k ? (uint32_t)m : k;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint64_t o = (uint64_t)qi * k + i;
+            if (key_words == 2) { out_keys[2 * o] = all[i].khi; out_keys[2 * o + 1] = all[i].klo; }
+            else out_keys[o] = all[i].klo;
+            out_hamming[o] = all[i].h;
+            out_prefix_bits[o] = (uint16_t)(metric ? all[i].p : table_bytes * 8);
+        }
+        out_count[qi] = cnt;
+        free(all);
+    }
+    free(heaps);
+    free(cnts);
     return failed ? -1 : 0;
 }
 
