@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per step")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nbytes", type=int, default=8, help="code length in bytes (8 = 64-bit)")
-    ap.add_argument("--tq", type=int, default=8, help="queries per streaming pass (8|16|32); 8 keeps the scan HBM-bound")
+    ap.add_argument("--tq", type=int, default=8, help="queries per streaming pass (8|10|12|16); 8 keeps the scan HBM-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")

@@ -85,7 +85,7 @@ int isccsearch_create(int device_id, isccsearch_handle** out);
 int isccsearch_destroy(isccsearch_handle* h);
 const char* isccsearch_last_error(void);
 
-/* Options: "queries_per_pass" (8|16|32), "profile" (0|1: time every collect-scan launch with HIP
+/* Options: "queries_per_pass" (8|10|12|16), "profile" (0|1: time every collect-scan launch with HIP
  * events, read back through isccsearch_stats), "nontemporal" (0|1). */
 int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);
 int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset);

@@ -263,7 +263,6 @@ void launch_scan_tq(int tq, int mode, bool nt, dim3 grid, hipStream_t st, const 
         case 8: launch_scan_mode<W, MASK, 8>(mode, nt, grid, st, p); break;
         case 10: launch_scan_mode<W, MASK, 10>(mode, nt, grid, st, p); break;
         case 12: launch_scan_mode<W, MASK, 12>(mode, nt, grid, st, p); break;
-        case 32: launch_scan_mode<W, MASK, 32>(mode, nt, grid, st, p); break;
         default: launch_scan_mode<W, MASK, 16>(mode, nt, grid, st, p); break;
     }
 }
@@ -663,7 +662,8 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!h || !name) return fail(-EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(name, "queries_per_pass")) {
-        if (value != 8 && value != 10 && value != 12 && value != 16 && value != 32) return fail(-EINVAL, "queries_per_pass must be 8, 10, 12, 16 or 32");
+        // 32 is not offered: its query registers spill to scratch, which the asm-issued loads forbid
+        if (value != 8 && value != 10 && value != 12 && value != 16) return fail(-EINVAL, "queries_per_pass must be 8, 10, 12 or 16");
         h->tq = (int)value;
         h->stats.queries_per_pass = (uint32_t)value;
         return 0;

@@ -91,13 +91,61 @@ __device__ __forceinline__ u32x4 load16(const uint64_t* p) {
 
 // Streaming loads of the scan kernel, issued from inline asm so that the PREFETCH stays in flight:
 // hipcc's own s_waitcnt insertion drained it at the loop head (vmcnt(0) in front of the next
-// prefetch's address arithmetic).  The compiler does not count these loads, so every use of a
-// destination goes through wait_tile() first (counted s_waitcnt vmcnt + register ties).
-// saddr form: 64-bit scalar base + 32-bit per-lane byte offset.
-template <bool NT>
-__device__ __forceinline__ void gload16(u32x4& dst, const void* sbase, uint32_t voff) {
-    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+// prefetch's address arithmetic).  hipcc neither counts nor pads what is inside an asm statement
+// (cdna_hip_programming.md section 5.7), so:
+//   * every use of a destination goes through wait_tile() first (counted s_waitcnt vmcnt + "+v" ties);
+//   * the string opens with `s_nop 4`: the scalar bases may come straight from v_readfirstlane /
+//     v_readlane (SGPR spill reloads), and a VALU-written SGPR needs 5 wait states before a VMEM
+//     instruction reads it -- without the pad the load used a stale base (wrong rows, or a fault);
+//   * outputs are early-clobber: a destination must not share a register with a later load's operand;
+//   * kernels using these loads must have NO scratch and NO VGPR spills (a compiler copy of a
+//     destination between load and wait would read garbage): tools/kernel_resources.py checks it.
+// All U*W loads of a tile are ONE statement.  saddr form: 64-bit scalar column base + one 32-bit per-lane
+// byte offset + immediate u*1024 (each wave reads U KiB contiguous per column).
+#define ISK_LD(dst, off, base, imm, nt) "global_load_dwordx4 " dst ", " off ", " base " offset:" imm nt "\n\t"
+template <bool NT, int U, int W>
+__device__ __forceinline__ void load_tile_asm(u32x4 (&v)[U][W], const void* const (&tb)[W], uint32_t voff) {
+    if constexpr (W == 1) {
+        static_assert(U == 4, "tile shape");
+        if constexpr (NT)
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%4", "%5", "0", " nt") ISK_LD("%1", "%4", "%5", "1024", " nt")
+                         ISK_LD("%2", "%4", "%5", "2048", " nt") ISK_LD("%3", "%4", "%5", "3072", " nt")
+                         : "=&v"(v[0][0]), "=&v"(v[1][0]), "=&v"(v[2][0]), "=&v"(v[3][0]) : "v"(voff), "s"(tb[0]) : "memory");
+        else
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%4", "%5", "0", "") ISK_LD("%1", "%4", "%5", "1024", "")
+                         ISK_LD("%2", "%4", "%5", "2048", "") ISK_LD("%3", "%4", "%5", "3072", "")
+                         : "=&v"(v[0][0]), "=&v"(v[1][0]), "=&v"(v[2][0]), "=&v"(v[3][0]) : "v"(voff), "s"(tb[0]) : "memory");
+    } else if constexpr (W == 2) {
+        static_assert(U == 2, "tile shape");
+        if constexpr (NT)
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%4", "%5", "0", " nt") ISK_LD("%1", "%4", "%6", "0", " nt")
+                         ISK_LD("%2", "%4", "%5", "1024", " nt") ISK_LD("%3", "%4", "%6", "1024", " nt")
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]) : "v"(voff), "s"(tb[0]), "s"(tb[1]) : "memory");
+        else
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%4", "%5", "0", "") ISK_LD("%1", "%4", "%6", "0", "")
+                         ISK_LD("%2", "%4", "%5", "1024", "") ISK_LD("%3", "%4", "%6", "1024", "")
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]) : "v"(voff), "s"(tb[0]), "s"(tb[1]) : "memory");
+    } else if constexpr (W == 3) {
+        static_assert(U == 1, "tile shape");
+        if constexpr (NT)
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%3", "%4", "0", " nt") ISK_LD("%1", "%3", "%5", "0", " nt") ISK_LD("%2", "%3", "%6", "0", " nt")
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]) : "v"(voff), "s"(tb[0]), "s"(tb[1]), "s"(tb[2]) : "memory");
+        else
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%3", "%4", "0", "") ISK_LD("%1", "%3", "%5", "0", "") ISK_LD("%2", "%3", "%6", "0", "")
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]) : "v"(voff), "s"(tb[0]), "s"(tb[1]), "s"(tb[2]) : "memory");
+    } else {
+        static_assert(W == 4 && U == 1, "tile shape");
+        if constexpr (NT)
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%4", "%5", "0", " nt") ISK_LD("%1", "%4", "%6", "0", " nt")
+                         ISK_LD("%2", "%4", "%7", "0", " nt") ISK_LD("%3", "%4", "%8", "0", " nt")
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3])
+                         : "v"(voff), "s"(tb[0]), "s"(tb[1]), "s"(tb[2]), "s"(tb[3]) : "memory");
+        else
+            asm volatile("s_nop 4\n\t" ISK_LD("%0", "%4", "%5", "0", "") ISK_LD("%1", "%4", "%6", "0", "")
+                         ISK_LD("%2", "%4", "%7", "0", "") ISK_LD("%3", "%4", "%8", "0", "")
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3])
+                         : "v"(voff), "s"(tb[0]), "s"(tb[1]), "s"(tb[2]), "s"(tb[3]) : "memory");
+    }
 }
 // wait until at most N vector-memory operations of this wave are outstanding, then tie the tile's
 // registers to the wait so that no use can be scheduled above it
@@ -150,20 +198,22 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
     const uint32_t mlo = sgpr(p.mask_lo), mhi = sgpr(p.mask_hi);
 
     const uint64_t n_full = p.n_rows / TILE;
-    // per-lane byte offsets inside a tile (constant over the loop); the tile base stays scalar
-    uint32_t voff[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) voff[u] = tid * 16u + (uint32_t)u * (BLOCK * 16u);
+    // per-lane byte offset inside a tile (constant over the loop): wave w reads U KiB contiguous per column,
+    // load u of a lane sits u*1024 bytes further (immediate offset); the tile base stays scalar.
+    //   row(u, lane, r) = tile*TILE + wave*(U*128) + u*128 + lane*2 + r
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t voff = wave * (uint32_t)(U * 1024) + lane * 16u;
+    const uint32_t row_in_tile = wave * (uint32_t)(U * 128) + lane * 2u;
 
     auto load_tile = [&](u32x4 (&v)[U][W], uint64_t tile) {
+        const void* tb[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             // uniform tile base, forced into an SGPR pair for the saddr operand
             const uint64_t ta = reinterpret_cast<uint64_t>(p.col[w]) + tile * (uint64_t)(TILE * 8);
-            const char* tb = reinterpret_cast<const char*>(((uint64_t)sgpr((uint32_t)(ta >> 32)) << 32) | sgpr((uint32_t)ta));
-#pragma unroll
-            for (int u = 0; u < U; ++u) gload16<NT>(v[u][w], tb, voff[u]);
+            tb[w] = reinterpret_cast<const void*>(((uint64_t)sgpr((uint32_t)(ta >> 32)) << 32) | sgpr((uint32_t)ta));
         }
+        load_tile_asm<NT, U, W>(v, tb, voff);
     };
 
     auto process = [&](const u32x4 (&v)[U][W], uint64_t tile) {
@@ -191,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
             // query from the SGPR-resident queries (fully unrolled: no memory loads, no dynamic register
             // indexing), so a tile that takes this path costs about two plain tiles instead of the
             // ~16 a load-per-query loop cost.
-            const uint64_t base = tile * TILE + (uint64_t)tid * 2;
+            const uint64_t base = tile * TILE + row_in_tile;
             // launder the row registers: without this the compiler merges the rescoring below with
             // the fast path above (common subexpressions) and keeps all TQ*U*2 accumulators alive
             u32x4 r[U][W];
@@ -220,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                 if ((int32_t)mq >= 0) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const uint64_t row = base + (uint64_t)u * (BLOCK * 2);
+                        const uint64_t row = base + (uint64_t)u * 128;
                         if ((int32_t)a[u][0] >= 0) emit<MODE>(p, q0 + q, a[u][0] - bias[q], row);
                         if ((int32_t)a[u][1] >= 0) emit<MODE>(p, q0 + q, a[u][1] - bias[q], row + 1);
                     }

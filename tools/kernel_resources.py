@@ -8,6 +8,7 @@ import re
 import sys
 
 txt = open(sys.argv[1]).read()
+failed = False
 occ_key = "Occupancy \\[waves/SIMD\\]"
 scr_key = "ScratchSize \\[bytes/lane\\]"
 for b in re.split(r"Function Name: ", txt)[1:]:
@@ -20,5 +21,10 @@ for b in re.split(r"Function Name: ", txt)[1:]:
     def g(k):
         return re.search(k + r": (\d+)", b).group(1)
 
-    print("W=%s MASK=%s TQ=%-2s MODE=%s: SGPR=%-3s VGPR=%-3s waves/SIMD=%s sgpr_spill=%-3s vgpr_spill=%s scratch=%s" % (
-        W, MASK, TQ, MODE, g("TotalSGPRs"), g("VGPRs"), g(occ_key), g("SGPRs Spill"), g("VGPRs Spill"), g(scr_key)))
+    bad = "" if (g("VGPRs Spill") == "0" and g(scr_key) == "0") else "   <-- FORBIDDEN with asm-issued loads (scratch / VGPR spill)"
+    print("W=%s MASK=%s TQ=%-2s MODE=%s: SGPR=%-3s VGPR=%-3s waves/SIMD=%s sgpr_spill=%-3s vgpr_spill=%s scratch=%s%s" % (
+        W, MASK, TQ, MODE, g("TotalSGPRs"), g("VGPRs"), g(occ_key), g("SGPRs Spill"), g("VGPRs Spill"), g(scr_key), bad))
+    if bad:
+        failed = True
+
+sys.exit(1 if failed else 0)
