@@ -1,3 +1,5 @@
+"""Parity matrix on the GPU: every code length class x queries-per-pass x batch size against the oracle-backed model
+(kept from the hunt for the stale-SGPR-base bug; prints only mismatches, then `done`)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
