@@ -51,6 +51,21 @@ class BatchMatches:
         return iter(self._matches)
 
 
+def _drop_present(table, keys, words, nbytes):
+    """
+    usearch with multi=False keeps the ORIGINAL vector when a key is added again and skips the new one
+    silently (tests/test_usearch_add.py:53-62); inside one batch the first occurrence wins.
+    """
+    present = table.contains(keys)
+    _, first = np.unique(keys, return_index=True)
+    keep = np.zeros(len(keys), dtype=bool)
+    keep[first] = True
+    keep &= ~present
+    if keep.all():
+        return keys, words, nbytes
+    return keys[keep], words[keep], (None if nbytes is None else nbytes[keep])
+
+
 def _as_bytes(v):
     if isinstance(v, (bytes, bytearray, memoryview)):
         return bytes(v)
@@ -80,7 +95,9 @@ class HipNphdIndex:
         if len(keys) == 0:
             return
         words, nbytes = pack_bytes(codes, self._table.max_words)
-        self._table.add(keys, words, nbytes)
+        keys, words, nbytes = _drop_present(self._table, keys, words, nbytes)
+        if len(keys):
+            self._table.add(keys, words, nbytes)
 
     def remove(self, keys):
         # type: (int | list[int] | np.ndarray) -> int
@@ -143,6 +160,86 @@ class HipNphdIndex:
     def load(self, path):
         # type: (str) -> None
         self._table.load(path)
+
+    def reset(self):
+        self._table.drop()
+
+    close = reset
+
+
+class HipHammingIndex:
+    """
+    Fixed-length binary vectors, Hamming metric, 64-bit keys: the subset of
+    ``usearch.index.Index(ndim, metric=MetricKind.Hamming, dtype=ScalarKind.B1)`` that the reference's
+    characterisation tests pin (tests/test_usearch_{add,get,contains,remove,search}.py), always exact.
+    """
+
+    def __init__(self, engine, ndim):
+        # type: (object, int) -> None
+        if ndim % 8 or not 8 <= ndim <= 256:
+            raise ValueError("ndim must be a multiple of 8 bits up to 256")
+        self.ndim = ndim
+        self.nbytes = ndim // 8
+        self._table = engine.open_table(METRIC_HAMMING, 1, self.nbytes)
+
+    def _vectors(self, vectors):
+        arr = np.asarray(vectors, dtype=np.uint8)
+        if arr.ndim == 1:
+            arr = arr.reshape(1, -1)
+        if arr.ndim != 2 or arr.shape[1] != self.nbytes:
+            raise ValueError(f"vectors must have {self.nbytes} bytes ({self.ndim} bits)")
+        return arr
+
+    def add(self, keys, vectors):
+        # type: (int | list[int] | np.ndarray, np.ndarray) -> np.ndarray
+        keys = np.atleast_1d(np.asarray(keys, dtype=np.uint64))
+        arr = self._vectors(vectors)
+        if len(keys) != arr.shape[0]:
+            raise ValueError("keys and vectors differ in length")
+        words, _ = pack_bytes(arr, self._table.max_words)
+        k2, w2, _ = _drop_present(self._table, keys, words, None)
+        if len(k2):
+            self._table.add(k2, w2)
+        return keys
+
+    def remove(self, keys):
+        # type: (int | list[int] | np.ndarray) -> int
+        keys = np.atleast_1d(np.asarray(keys, dtype=np.uint64))
+        return self._table.remove(keys) if len(keys) else 0
+
+    def contains(self, keys):
+        # type: (int | list[int] | np.ndarray) -> bool | np.ndarray
+        if np.isscalar(keys):
+            return bool(self._table.contains(np.asarray([keys], dtype=np.uint64))[0])
+        return self._table.contains(np.asarray(keys, dtype=np.uint64))
+
+    def __contains__(self, key):
+        return self.contains(key)
+
+    def get(self, keys):
+        # type: (int | list[int]) -> np.ndarray | None | list
+        single = np.isscalar(keys)
+        arr = np.atleast_1d(np.asarray(keys, dtype=np.uint64))
+        words, nb = self._table.get(arr)
+        out = [np.frombuffer(unpack_words(words[i], self.nbytes), dtype=np.uint8) if nb[i] else None for i in range(len(arr))]
+        return out[0] if single else out
+
+    def __len__(self):
+        return self._table.size
+
+    size = property(lambda self: self._table.size)
+
+    def search(self, vectors, count=10):
+        # type: (np.ndarray, int) -> Matches | BatchMatches
+        if count < 1:
+            raise ValueError("`count` must be >= 1")
+        single = np.asarray(vectors).ndim == 1
+        arr = self._vectors(vectors)
+        q_words, _ = pack_bytes(arr, self._table.max_words)
+        keys, ham, pbits, cnt = self._table.search(q_words, None, count)
+        out = [Matches(keys[q, : cnt[q]].copy(), ham[q, : cnt[q]].astype(np.float32), ham[q, : cnt[q]].copy(), pbits[q, : cnt[q]].copy())
+               for q in range(arr.shape[0])]
+        return out[0] if single else BatchMatches(out)
 
     def reset(self):
         self._table.drop()
