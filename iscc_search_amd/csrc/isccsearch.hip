@@ -493,7 +493,7 @@ struct Batch {
                 if (!h->p_flags.p[ji * nq_pad + q]) continue;
                 Ctx c = make_ctx(ji);
                 h->stats.fallback_queries += 1;
-                if ((rc = h->d_misc.ensure(isk::HB + 8))) return rc;
+                if ((rc = h->d_misc.ensure(isk::HB + 256 + 16))) return rc;   // full histogram + one key-byte histogram
                 uint32_t* d_fh = reinterpret_cast<uint32_t*>(h->d_misc.p);
                 HIPOK(hipMemsetAsync(d_fh, 0, isk::HB * sizeof(uint32_t), h->stream));
                 isk::FullHistParams fp{};
@@ -504,32 +504,55 @@ struct Batch {
                 uint32_t fh[isk::HB];
                 HIPOK(hipMemcpyAsync(fh, d_fh, sizeof fh, hipMemcpyDeviceToHost, h->stream));
                 HIPOK(hipStreamSynchronize(h->stream));
-                uint64_t cum = 0;
+                uint64_t cum = 0, less = 0;
                 uint32_t tau = 256;
                 const uint64_t need = std::min<uint64_t>(k, s.n);
-                for (uint32_t b = 0; b < isk::NBINS; ++b) { cum += fh[b]; if (cum >= need) { tau = b; break; } }
-                // candidates with hamming <= tau: exactly `cum` rows, collected into a private buffer
-                if (cum > 0xFFFFFFFFull) return fail(-E2BIG, "tie class of %llu rows exceeds the fallback buffer", (unsigned long long)cum);
-                if ((rc = h->d_misc2.ensure((size_t)cum + 8))) return rc;
-                // rerun only the group holding q; every other slot of the group gets BIAS_NEVER
-                const uint32_t g = q / tq, ql = q - g * tq;
-                std::vector<uint32_t> hb(tq, isk::BIAS_NEVER);
-                hb[ql] = 0x7FFFFFFFu - tau;
-                HIPOK(hipMemcpyAsync(h->d_bias.p + (size_t)g * tq, hb.data(), tq * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-                HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE, 0, (size_t)tq * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
-                isk::ScanParams fsp = c.sp;
-                fsp.n_rows = s.n;
-                fsp.cap = (uint32_t)cum;
-                fsp.queries = h->d_queries.p + (size_t)g * tq * 4;
-                fsp.bias = h->d_bias.p + (size_t)g * tq;
-                fsp.cnt = h->d_cnt.p + (size_t)g * tq * isk::CNT_STRIDE;
-                // slot ql of the group appends at cand[ql*cap + i]: bias the base so that lands at d_misc2[i]
-                fsp.cand = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)ql * fsp.cap * 8);
-                launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n), 1), h->stream, fsp);
-                HIPOK(hipStreamSynchronize(h->stream));   // hb is pageable host memory
+                for (uint32_t b = 0; b < isk::NBINS; ++b) { less = cum; cum += fh[b]; if (cum >= need) { tau = b; break; } }
+                // `less` rows lie strictly below tau, `cum - less` rows tie at tau.  When the tie class is too
+                // large to collect, pin down the r = need - less smallest KEYS of it by radix select over
+                // the table (8 bits of the key per pass) until what must be collected fits the buffer.
+                const uint32_t small_cap = std::max<uint32_t>(cap, 65536);
+                isk::FbParams fb{};
+                for (uint32_t w = 0; w < j.W; ++w) fb.col[w] = s.col[w];
+                fb.keys = s.keys; fb.n_rows = s.n; fb.query = h->d_queries.p + (size_t)q * 4;
+                fb.W = j.W; fb.KW = (uint32_t)t.key_words; fb.mask_last = j.mask_last; fb.tau = tau;
+                fb.d = 0; fb.phi = 0; fb.plo = 0;
+                uint64_t collect = cum;              // rows the final collect will append
+                uint64_t r_need = need - less, tie = cum - less;
+                while (collect > small_cap && fb.d < t.key_words * 8 && r_need < tie) {
+                    uint32_t* d_kh = reinterpret_cast<uint32_t*>(h->d_misc.p) + isk::HB;
+                    HIPOK(hipMemsetAsync(d_kh, 0, 256 * sizeof(uint32_t), h->stream));
+                    fb.ghist = d_kh;
+                    if (t.key_words == 2) hipLaunchKernelGGL(isk::fb_keyhist_kernel<2>, dim3(fgrid), dim3(isk::BLOCK), 0, h->stream, fb);
+                    else hipLaunchKernelGGL(isk::fb_keyhist_kernel<1>, dim3(fgrid), dim3(isk::BLOCK), 0, h->stream, fb);
+                    uint32_t kh[256];
+                    HIPOK(hipMemcpyAsync(kh, d_kh, sizeof kh, hipMemcpyDeviceToHost, h->stream));
+                    HIPOK(hipStreamSynchronize(h->stream));
+                    uint64_t below = 0;
+                    uint32_t digit = 255;
+                    for (uint32_t b = 0; b < 256; ++b) { if (below + kh[b] >= r_need) { digit = b; break; } below += kh[b]; }
+                    // keys with a smaller byte are all taken; the bucket `digit` holds the cut
+                    less += below;
+                    r_need -= below;
+                    tie = kh[digit];
+                    const int sh = 56 - 8 * (t.key_words == 2 ? (fb.d < 8 ? fb.d : fb.d - 8) : fb.d);
+                    if (t.key_words == 2 && fb.d < 8) fb.phi |= (uint64_t)digit << sh;
+                    else fb.plo |= (uint64_t)digit << sh;
+                    fb.d += 1;
+                    collect = less + tie;            // everything below the cut + the whole cut bucket
+                }
+                if (collect > 0xFFFFFFFFull) return fail(-E2BIG, "tie class of %llu rows exceeds the fallback buffer", (unsigned long long)collect);
+                if ((rc = h->d_misc2.ensure((size_t)collect + 8))) return rc;
+                // collect into a private buffer addressed as candidate list of query q
+                HIPOK(hipMemsetAsync(h->d_cnt.p + (size_t)q * isk::CNT_STRIDE, 0, sizeof(uint32_t), h->stream));
+                fb.cnt = h->d_cnt.p + (size_t)q * isk::CNT_STRIDE;
+                fb.cand = h->d_misc2.p;
+                fb.cap = (uint32_t)collect;
+                if (t.key_words == 2) hipLaunchKernelGGL(isk::fb_collect_kernel<2>, dim3(fgrid), dim3(isk::BLOCK), 0, h->stream, fb);
+                else hipLaunchKernelGGL(isk::fb_collect_kernel<1>, dim3(fgrid), dim3(isk::BLOCK), 0, h->stream, fb);
                 isk::SelectParams fsl = c.sl;
-                fsl.cnt = h->d_cnt.p; fsl.cap = fsp.cap; fsl.q_base = q;
-                fsl.cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)q * fsp.cap * 8);
+                fsl.cnt = h->d_cnt.p; fsl.cap = fb.cap; fsl.q_base = q;
+                fsl.cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(h->d_misc2.p) - (uintptr_t)q * fsl.cap * 8);
                 HIPOK(hipMemsetAsync(c.sl.overflow + q, 0, sizeof(uint32_t), h->stream));
                 launch_select(fsl, 1);
                 HIPOK(hipGetLastError());

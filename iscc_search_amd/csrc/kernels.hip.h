@@ -637,6 +637,75 @@ __global__ __launch_bounds__(BLOCK) void fullhist_kernel(const FullHistParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Overflow fallback for tie classes too large to collect: radix select on the KEY over the rows of
+// the table itself.  One query at a time; plain (unpipelined) scans -- this path only runs for
+// adversarial data (e.g. millions of identical codes).
+//   fb_keyhist_kernel  histogram of key byte `d` over rows with hamming == tau whose first d key
+//                      bytes equal the selected prefix
+//   fb_collect_kernel  append rows with hamming < tau, or hamming == tau and top-d key bytes <= prefix
+// ---------------------------------------------------------------------------------------------
+struct FbParams {
+    const uint64_t* col[4];
+    const uint64_t* keys;
+    uint64_t n_rows;
+    const uint64_t* query;    // [4]
+    uint32_t W, KW;
+    uint64_t mask_last;
+    uint32_t tau;
+    int d;                    // key bytes already fixed
+    uint64_t phi, plo;        // the fixed prefix (as a key with the lower bytes cleared)
+    uint32_t* ghist;          // [256]  (fb_keyhist_kernel)
+    uint32_t* cnt;            // [1]    (fb_collect_kernel)
+    uint64_t* cand;           // [cap]
+    uint32_t cap;
+};
+__device__ __forceinline__ uint32_t fb_hamming(const FbParams& p, const uint64_t (&qw)[4], uint64_t r) {
+    uint32_t h = 0;
+    for (uint32_t w = 0; w < p.W; ++w) {
+        uint64_t x = p.col[w][r] ^ qw[w];
+        if (w == p.W - 1) x &= p.mask_last;
+        h += (uint32_t)__builtin_popcountll(x);
+    }
+    return h;
+}
+template <int KW>
+__global__ __launch_bounds__(BLOCK) void fb_keyhist_kernel(const FbParams p) {
+    __shared__ uint32_t hist[256];
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    uint64_t qw[4];
+    for (uint32_t w = 0; w < 4; ++w) qw[w] = w < p.W ? p.query[w] : 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + tid; r < p.n_rows; r += (uint64_t)gridDim.x * BLOCK) {
+        if (fb_hamming(p, qw, r) != p.tau) continue;
+        uint64_t khi, klo, thi, tlo;
+        load_key<KW>(p.keys, r, khi, klo);
+        key_top<KW>(khi, klo, p.d, thi, tlo);
+        if (thi == p.phi && tlo == p.plo) atomicAdd(&hist[key_digit<KW>(khi, klo, p.d)], 1u);
+    }
+    __syncthreads();
+    if (hist[tid]) atomicAdd(&p.ghist[tid], hist[tid]);
+}
+template <int KW>
+__global__ __launch_bounds__(BLOCK) void fb_collect_kernel(const FbParams p) {
+    const uint32_t tid = threadIdx.x;
+    uint64_t qw[4];
+    for (uint32_t w = 0; w < 4; ++w) qw[w] = w < p.W ? p.query[w] : 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + tid; r < p.n_rows; r += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t h = fb_hamming(p, qw, r);
+        if (h > p.tau) continue;
+        if (h == p.tau && p.d > 0) {
+            uint64_t khi, klo, thi, tlo;
+            load_key<KW>(p.keys, r, khi, klo);
+            key_top<KW>(khi, klo, p.d, thi, tlo);
+            if (thi > p.phi || (thi == p.phi && tlo > p.plo)) continue;
+        }
+        const uint32_t slot = atomicAdd(p.cnt, 1u);
+        if (slot < p.cap) p.cand[slot] = ((uint64_t)h << 48) | r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // merge_kernel: per query, k-way merge of n_lists record lists, each sorted by (dist_rank, key).
 //   rank of an element = its position in its own list + the number of elements of every other
 //   list that sort before it (binary search); ranks are distinct because keys are.

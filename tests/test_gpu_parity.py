@@ -114,17 +114,25 @@ def test_hamming64_heavy_ties(hip_engine):
         t.drop()
 
 
-def test_all_identical_codes_take_the_exact_fallback(hip_engine):
-    """Every row equal: the tie class is the whole table, far beyond the candidate buffer."""
-    n, k = 200000, 10
-    t = hip_engine.open_table(METRIC_HAMMING, 1, 8)
+@pytest.mark.parametrize("key_words", [1, 2])
+def test_all_identical_codes_take_the_exact_fallback(hip_engine, key_words):
+    """Every row equal: the tie class is the whole table, far beyond the candidate buffer AND beyond what
+    the fallback collects in one go -> radix select on the key over the table itself."""
+    n, k = 300000, 10
+    rng = np.random.default_rng(3)
+    t = hip_engine.open_table(METRIC_HAMMING, key_words, 8)
     try:
         words = np.full((n, 1), 0xDEADBEEFCAFEF00D, dtype=np.uint64)
-        keys = np.random.default_rng(3).permutation(np.arange(n, dtype=np.uint64) * np.uint64(7) + np.uint64(5))
+        words[::1000] ^= np.uint64(1)                    # a few rows one bit away
+        if key_words == 2:
+            keys = np.stack([rng.integers(0, 5, size=n).astype(np.uint64), rng.permutation(n).astype(np.uint64) * np.uint64(2**40 + 7)], axis=1)
+        else:
+            keys = rng.permutation(np.arange(n, dtype=np.uint64) * np.uint64(2**33 + 5) + np.uint64(5))
         t.add(keys, words)
         before = hip_engine.stats()["fallback_queries"]
-        q = np.array([[0xDEADBEEFCAFEF00D], [0x0123456789ABCDEF]], dtype=np.uint64)
+        q = np.array([[0xDEADBEEFCAFEF00D], [0xDEADBEEFCAFEF00C], [0x0123456789ABCDEF]], dtype=np.uint64)
         _check(t, keys, words, None, q, None, k, METRIC_HAMMING)
+        _check(t, keys, words, None, q, None, 700, METRIC_HAMMING)
         assert hip_engine.stats()["fallback_queries"] > before
     finally:
         t.drop()
