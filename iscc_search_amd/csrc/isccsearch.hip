@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -129,8 +130,14 @@ uint32_t next_pow2(uint32_t v) { uint32_t p = 2; while (p < v) p <<= 1; return p
 
 }  // namespace
 
+struct PendingSearch;
 struct isccsearch_handle {
     std::mutex mu;
+    // combining queue of isccsearch_search callers
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::vector<PendingSearch*> pending;
+    bool leader_active = false;
     int device = 0;
     int cus = 256;
     hipStream_t stream = nullptr;
@@ -1074,22 +1081,16 @@ int isccsearch_get(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
     return 0;
 }
 
-int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
-                      const uint8_t* q_nbytes, uint32_t k,
-                      uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
-    if (!h) return fail(-EINVAL, "handle is NULL");
-    if (k < 1) return fail(-EINVAL, "`count` must be >= 1");
-    if (k > ISCCSEARCH_MAX_K) return fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", k, ISCCSEARCH_MAX_K);
-    if (nq == 0) return 0;
-    if (!q_words || !out_keys || !out_hamming || !out_prefix_bits || !out_count) return fail(-EINVAL, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+// The search itself; h->mu is held by the caller.
+static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                         const uint8_t* q_nbytes, uint32_t k,
+                         uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
     Table* tp;
     int rc = get_table(h, table, tp);
     if (rc) return rc;
     Table& t = *tp;
     if ((rc = check_query_lengths(t, nq, q_nbytes))) return rc;
     HIPOK(hipSetDevice(h->device));
-    h->stats.searches += 1;
     h->stats.queries += nq;
 
     // group queries by byte length (NPHD prefix length differs per class)
@@ -1143,6 +1144,128 @@ int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const u
         pos = end;
     }
     return 0;
+}
+
+// Searches arriving from many threads are COMBINED: the reference calls `search` once per query unit from
+// FastAPI's thread pool (usearch/index.py:786-806, docs/explanation/architecture.md:120-126), and a
+// streaming pass costs the same for one query as for T_q.  The first caller becomes the leader, takes every
+// request waiting on the same (table, k) and runs them as ONE batch; the others sleep until their slice of
+// the results has been written.  A single-threaded caller pays nothing for this.
+struct PendingSearch {
+    uint32_t table, nq, k;
+    const uint64_t* q_words;
+    const uint8_t* q_nbytes;
+    uint64_t* out_keys;
+    uint32_t* out_hamming;
+    uint16_t* out_prefix_bits;
+    uint32_t* out_count;
+    int rc = 0;
+    bool done = false;
+    std::string err;
+};
+
+namespace {
+void run_combined(isccsearch_handle* h, std::vector<PendingSearch*>& reqs) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::vector<bool> handled(reqs.size(), false);
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        if (handled[i]) continue;
+        // requests sharing table and k (and therefore key width / words per query)
+        std::vector<size_t> grp;
+        for (size_t j = i; j < reqs.size(); ++j)
+            if (!handled[j] && reqs[j]->table == reqs[i]->table && reqs[j]->k == reqs[i]->k) { grp.push_back(j); handled[j] = true; }
+        h->stats.searches += grp.size();
+        Table* tp = nullptr;
+        int rc = get_table(h, reqs[i]->table, tp);
+        // validate each request on its own so that one bad caller does not fail the others
+        std::vector<size_t> ok;
+        for (size_t j : grp) {
+            PendingSearch* r = reqs[j];
+            int rj = rc ? rc : check_query_lengths(*tp, r->nq, r->q_nbytes);
+            if (rj) { r->rc = rj; r->err = g_last_error; }
+            else ok.push_back(j);
+        }
+        if (ok.empty()) continue;
+        if (ok.size() == 1) {
+            PendingSearch* r = reqs[ok[0]];
+            r->rc = search_locked(h, r->table, r->nq, r->q_words, r->q_nbytes, r->k, r->out_keys, r->out_hamming, r->out_prefix_bits, r->out_count);
+            if (r->rc) r->err = g_last_error;
+            continue;
+        }
+        const Table& t = *tp;
+        const uint32_t k = reqs[i]->k;
+        const int MW = t.max_words, KW = t.key_words;
+        size_t total = 0;
+        for (size_t j : ok) total += reqs[j]->nq;
+        std::vector<uint64_t> qw(total * MW), okeys(total * k * KW);
+        std::vector<uint8_t> qn(t.metric == ISCCSEARCH_METRIC_NPHD ? total : 0);
+        std::vector<uint32_t> oh(total * k), oc(total);
+        std::vector<uint16_t> op(total * k);
+        size_t off = 0;
+        for (size_t j : ok) {
+            PendingSearch* r = reqs[j];
+            memcpy(&qw[off * MW], r->q_words, (size_t)r->nq * MW * 8);
+            if (!qn.empty()) memcpy(&qn[off], r->q_nbytes, r->nq);
+            off += r->nq;
+        }
+        const int rg = search_locked(h, reqs[i]->table, (uint32_t)total, qw.data(), qn.empty() ? nullptr : qn.data(), k,
+                                     okeys.data(), oh.data(), op.data(), oc.data());
+        const std::string eg = rg ? g_last_error : std::string();
+        off = 0;
+        for (size_t j : ok) {
+            PendingSearch* r = reqs[j];
+            r->rc = rg;
+            r->err = eg;
+            if (!rg) {
+                memcpy(r->out_keys, &okeys[off * k * KW], (size_t)r->nq * k * KW * 8);
+                memcpy(r->out_hamming, &oh[off * k], (size_t)r->nq * k * 4);
+                memcpy(r->out_prefix_bits, &op[off * k], (size_t)r->nq * k * 2);
+                memcpy(r->out_count, &oc[off], (size_t)r->nq * 4);
+            }
+            off += r->nq;
+        }
+    }
+}
+}  // namespace
+
+int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                      const uint8_t* q_nbytes, uint32_t k,
+                      uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (k < 1) return fail(-EINVAL, "`count` must be >= 1");
+    if (k > ISCCSEARCH_MAX_K) return fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", k, ISCCSEARCH_MAX_K);
+    if (nq == 0) return 0;
+    if (!q_words || !out_keys || !out_hamming || !out_prefix_bits || !out_count) return fail(-EINVAL, "NULL argument");
+    PendingSearch me;
+    me.table = table; me.nq = nq; me.k = k; me.q_words = q_words; me.q_nbytes = q_nbytes;
+    me.out_keys = out_keys; me.out_hamming = out_hamming; me.out_prefix_bits = out_prefix_bits; me.out_count = out_count;
+    {
+        std::unique_lock<std::mutex> ql(h->qmu);
+        h->pending.push_back(&me);
+        if (h->leader_active) {
+            h->qcv.wait(ql, [&] { return me.done; });
+            if (me.rc) g_last_error = me.err;
+            return me.rc;
+        }
+        h->leader_active = true;
+    }
+    // leader: serve rounds until the queue is empty (my own request is in the first round)
+    for (;;) {
+        std::vector<PendingSearch*> round;
+        {
+            std::unique_lock<std::mutex> ql(h->qmu);
+            if (h->pending.empty()) { h->leader_active = false; break; }
+            round.swap(h->pending);
+        }
+        run_combined(h, round);
+        {
+            std::unique_lock<std::mutex> ql(h->qmu);
+            for (PendingSearch* r : round) r->done = true;
+        }
+        h->qcv.notify_all();
+    }
+    if (me.rc) g_last_error = me.err;
+    return me.rc;
 }
 
 int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,

@@ -146,3 +146,64 @@ def test_concurrent_searches_and_adds_are_serialised_safely(hip_engine):
     assert not errors, errors
     assert t.size == n + 10_000
     t.drop()
+
+
+def test_concurrent_single_query_callers_are_combined_and_exact(hip_engine, big):
+    """The reference issues one search per query unit from a thread pool; concurrent callers share passes."""
+    import threading
+    import time
+
+    q, _ = _queries(64)
+    expected = big.search(q, None, K)
+    out = [None] * 64
+    errors = []
+
+    def worker(i):
+        try:
+            out[i] = big.search(q[i : i + 1], None, K)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(64)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    concurrent_s = time.perf_counter() - t0
+    assert not errors, errors
+    for i in range(64):
+        for a, b in zip(out[i], expected):
+            np.testing.assert_array_equal(a[0], b[i])
+    # a mixed crowd: different k values and one invalid request must not disturb the others
+    res = {}
+
+    def mixed(i):
+        try:
+            res[i] = big.search(q[i : i + 2], None, 5 + (i % 3))
+        except ValueError as e:
+            res[i] = e
+
+    def bad():
+        try:
+            big.search(np.zeros((1, 2), dtype=np.uint64), None, 5)
+        except ValueError as e:
+            res["bad"] = e
+
+    threads = [threading.Thread(target=mixed, args=(i,)) for i in range(12)] + [threading.Thread(target=bad)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert isinstance(res["bad"], ValueError)
+    for i in range(12):
+        kk = 5 + (i % 3)
+        np.testing.assert_array_equal(res[i][0], expected[0][i : i + 2, :kk])
+        np.testing.assert_array_equal(res[i][1], expected[1][i : i + 2, :kk])
+    # sequential single-query calls for comparison (informational; combining must not be slower)
+    t0 = time.perf_counter()
+    for i in range(64):
+        big.search(q[i : i + 1], None, K)
+    sequential_s = time.perf_counter() - t0
+    print(f"64 single-query searches over 100M rows: sequential {sequential_s*1e3:.1f} ms, 64 threads {concurrent_s*1e3:.1f} ms")
+    assert concurrent_s < sequential_s * 1.2
