@@ -1242,28 +1242,28 @@ int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const u
     {
         std::unique_lock<std::mutex> ql(h->qmu);
         h->pending.push_back(&me);
-        if (h->leader_active) {
-            h->qcv.wait(ql, [&] { return me.done; });
-            if (me.rc) g_last_error = me.err;
-            return me.rc;
+        for (;;) {
+            if (me.done) {
+                if (me.rc) g_last_error = me.err;
+                return me.rc;
+            }
+            if (!h->leader_active) { h->leader_active = true; break; }   // nobody is serving: lead the next round
+            h->qcv.wait(ql);
         }
-        h->leader_active = true;
     }
-    // leader: serve rounds until the queue is empty (my own request is in the first round)
-    for (;;) {
-        std::vector<PendingSearch*> round;
-        {
-            std::unique_lock<std::mutex> ql(h->qmu);
-            if (h->pending.empty()) { h->leader_active = false; break; }
-            round.swap(h->pending);
-        }
-        run_combined(h, round);
-        {
-            std::unique_lock<std::mutex> ql(h->qmu);
-            for (PendingSearch* r : round) r->done = true;
-        }
-        h->qcv.notify_all();
+    // leader of exactly one round (it contains my own request), then hand over to a waiter
+    std::vector<PendingSearch*> round;
+    {
+        std::unique_lock<std::mutex> ql(h->qmu);
+        round.swap(h->pending);
     }
+    run_combined(h, round);
+    {
+        std::unique_lock<std::mutex> ql(h->qmu);
+        for (PendingSearch* r : round) r->done = true;
+        h->leader_active = false;
+    }
+    h->qcv.notify_all();
     if (me.rc) g_last_error = me.err;
     return me.rc;
 }

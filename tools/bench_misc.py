@@ -25,7 +25,7 @@ def timeit(fn, reps=10, warm=2):
 
 
 def main():
-    what = set(sys.argv[1:]) or {"latency", "small", "simprint", "mixed"}
+    what = set(sys.argv[1:]) or {"latency", "small", "simprint", "mixed", "threads"}
     eng = HipEngine(0)
     rng = np.random.default_rng(0)
     if "latency" in what:
@@ -59,6 +59,31 @@ def main():
                 dt = timeit(lambda: t.search(q, None, k), reps=3, warm=1)
                 print(f"simprint: {n} x {nbytes*8}-bit (128-bit keys), nq={nq}, k={k}: {dt*1e3:9.3f} ms/call ({nq/dt:8.0f} qps)")
             t.drop()
+    if "threads" in what:
+        # the reference's call shape under load: many threads, ONE query per call (k = 100 = its default limit)
+        import threading
+
+        t = eng.open_table(_lib.METRIC_HAMMING, 1, 8)
+        t.add_synthetic(8, 100_000_000, 1)
+        for nthreads in (1, 4, 16, 64):
+            stop = time.perf_counter() + 2.0
+            counts = [0] * nthreads
+
+            def loop(i):
+                r = np.random.default_rng(i)
+                while time.perf_counter() < stop:
+                    t.search(r.integers(0, 2**64, size=(1, 1), dtype=np.uint64), None, 100)
+                    counts[i] += 1
+
+            ths = [threading.Thread(target=loop, args=(i,)) for i in range(nthreads)]
+            t0 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            dt = time.perf_counter() - t0
+            print(f"threads: {nthreads:3d} callers x 1 query/call, k=100, 100M x 64-bit: {sum(counts)/dt:9.0f} queries/s")
+        t.drop()
     if "mixed" in what:
         t = eng.open_table(_lib.METRIC_NPHD, 1, 32)
         for nb, n in ((8, 40_000_000), (16, 20_000_000), (24, 10_000_000), (32, 30_000_000)):
