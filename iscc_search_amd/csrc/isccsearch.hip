@@ -262,7 +262,8 @@ void launch_scan_nt(bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p
 template <int W, bool MASK, int TQ>
 void launch_scan_mode(int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     if (mode == isk::MODE_COLLECT) launch_scan_nt<W, MASK, TQ, isk::MODE_COLLECT>(nt, grid, st, p);
-    else launch_scan_nt<W, MASK, TQ, isk::MODE_HIST>(nt, grid, st, p);
+    else if (mode == isk::MODE_HIST) launch_scan_nt<W, MASK, TQ, isk::MODE_HIST>(nt, grid, st, p);
+    else launch_scan_nt<W, MASK, TQ, isk::MODE_BOTH>(nt, grid, st, p);
 }
 template <int W, bool MASK>
 void launch_scan_tq(int tq, int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
@@ -446,28 +447,42 @@ struct Batch {
             //    cost balances the candidate handling it saves the full scan:
             //    S_last ~ sqrt(cost * 4096 * k * n).
             const double balance = std::sqrt((double)h->sample_cost / 100.0 * 4096.0 * (double)k * (double)s.n);
-            const uint64_t s_last = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, (uint64_t)balance));
+            const uint64_t tile_rows = (uint64_t)tile_rows_for((int)j.W);
+            uint64_t s_last = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, (uint64_t)balance));
+            // the LAST level also collects (MODE_BOTH), so the streaming pass starts where it ended: keep that
+            // boundary on a tile edge; a sample that covers the whole segment leaves nothing to stream
+            if (s_last < s.n) s_last = s_last / tile_rows * tile_rows;
+            if (s_last + tile_rows > s.n) s_last = s.n;
             const uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;
+            HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
+            uint64_t collected_to = 0;            // rows [0, collected_to) already have their candidates appended
+            sp.row_begin = 0;
             for (uint64_t sample = s0; sample < s_last;) {
                 sample = std::min<uint64_t>(s_last, sample * growth);
+                const bool last = sample == s_last;
                 HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
                 sp.n_rows = sample;
-                launch_scan((int)j.W, j.mask, tq, isk::MODE_HIST, h->nontemporal, dim3(scan_grid_x(h, j.W, sample, groups, true), groups), h->stream, sp);
+                launch_scan((int)j.W, j.mask, tq, last ? isk::MODE_BOTH : isk::MODE_HIST, h->nontemporal,
+                            dim3(scan_grid_x(h, j.W, sample, groups, true), groups), h->stream, sp);
                 isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, sample)};
                 hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
                 h->stats.sample_bytes += sample * 8 * j.W * groups;
+                if (last) collected_to = sample;
             }
 
-            // 3. the streaming pass: collect every row within the threshold
-            HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
-            sp.n_rows = s.n;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
-            launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n, groups), groups), h->stream, sp);
-            if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
-            h->stats.scan_launches += 1;
-            h->stats.scan_passes += groups;
-            h->stats.scan_bytes += s.n * 8 * j.W * groups;
+            // 3. the streaming pass: collect every remaining row within the threshold
+            if (collected_to < s.n) {
+                sp.row_begin = collected_to;
+                sp.n_rows = s.n;
+                const uint64_t rows = s.n - collected_to;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
+                launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+                h->stats.scan_launches += 1;
+                h->stats.scan_passes += groups;
+                h->stats.scan_bytes += rows * 8 * j.W * groups;
+            }
 
             // 4. exact select of the k best candidates per query (flags candidate-list overflow)
             launch_select(c.sl, nq);

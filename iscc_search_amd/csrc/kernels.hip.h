@@ -38,8 +38,9 @@ constexpr uint32_t CNT_STRIDE = 32;   // one candidate counter per 128-byte line
                                       // words of one line serialise at the memory side (~90 M/s per line)
 constexpr uint32_t BIT31 = 0x80000000u;
 constexpr uint32_t BIAS_NEVER = 0x80000000u;  // bias + h always has bit 31 set: never a candidate
-constexpr int MODE_COLLECT = 0;
-constexpr int MODE_HIST = 1;
+constexpr int MODE_COLLECT = 0;   // append candidates
+constexpr int MODE_HIST = 1;      // count candidates per hamming distance
+constexpr int MODE_BOTH = 2;      // both (last sample level: its rows are not scanned again)
 
 struct Record {            // == isccsearch_record (24 bytes)
     uint64_t key_hi;
@@ -56,7 +57,8 @@ template <int W> constexpr int tile_rows() { return BLOCK * 2 * TileCfg<W>::U; }
 
 struct ScanParams {
     const uint64_t* col[4];   // segment columns (word-major)
-    uint64_t n_rows;          // rows [0, n_rows) are scanned
+    uint64_t row_begin;       // first row scanned (a multiple of the tile size)
+    uint64_t n_rows;          // rows [row_begin, n_rows) are scanned
     const uint64_t* queries;  // [nq_pad][4] big-endian packed query words
     const uint32_t* bias;     // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries)
     uint32_t* cnt;            // [nq_pad * CNT_STRIDE] candidates appended so far (MODE_COLLECT)
@@ -160,12 +162,11 @@ __device__ __forceinline__ void wait_tile(u32x4 (&v)[U][W]) {
 
 template <int MODE>
 __device__ __forceinline__ void emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
-    if constexpr (MODE == MODE_COLLECT) {
+    if constexpr (MODE == MODE_COLLECT || MODE == MODE_BOTH) {
         const uint32_t slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
         if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)h << 48) | row;
-    } else {
-        atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
     }
+    if constexpr (MODE == MODE_HIST || MODE == MODE_BOTH) atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
     // between; more outstanding operations only make the counted wait stricter, never weaker.)
     {
         u32x4 va[U][W], vb[U][W];
-        uint64_t tile = blockIdx.x;
+        uint64_t tile = p.row_begin / TILE + blockIdx.x;
         if (tile < n_full) {
             const uint64_t last = n_full - 1;
             load_tile(va, tile);
