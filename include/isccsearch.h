@@ -86,7 +86,7 @@ int isccsearch_destroy(isccsearch_handle* h);
 const char* isccsearch_last_error(void);
 
 /* Options: "queries_per_pass" (8|10|12|16), "profile" (0|1: time every collect-scan launch with HIP
- * events, read back through isccsearch_stats), "nontemporal" (0|1). */
+ * events, read back through isccsearch_stats_get); tuning: "blocks_per_cu", "boot_rows", "sample_cost". */
 int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);
 int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset);
 

@@ -256,8 +256,10 @@ int ensure_index(H* h, Table& t) {
 // ------------------------------------------------------------------------------------------
 template <int W, bool MASK, int TQ, int MODE>
 void launch_scan_nt(bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
-    if (nt) hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true>), grid, dim3(isk::BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, false>), grid, dim3(isk::BLOCK), 0, st, p);
+    // only the non-temporal variant is instantiated: plain loads measured no faster and
+    // every extra variant costs build time
+    (void)nt;
+    hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true>), grid, dim3(isk::BLOCK), 0, st, p);
 }
 template <int W, bool MASK, int TQ>
 void launch_scan_mode(int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
