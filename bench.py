@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per step")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nbytes", type=int, default=8, help="code length in bytes (8 = 64-bit)")
+    ap.add_argument("--metric", choices=["hamming", "nphd"], default="hamming", help="table metric (nphd: every row --nbytes long, queries too)")
     ap.add_argument("--tq", type=int, default=8, help="queries per streaming pass (8|10|12|16); 8 keeps the scan HBM-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
@@ -115,7 +116,9 @@ def main():
     for kv in args.opt:
         name, _, val = kv.partition("=")
         engine.set_option(name, int(val))
-    table = engine.open_table(_lib.METRIC_HAMMING, 1, args.nbytes)
+    nphd = args.metric == "nphd"
+    table = engine.open_table(_lib.METRIC_NPHD if nphd else _lib.METRIC_HAMMING, 1, args.nbytes)
+    q_nbytes = np.full(args.queries, args.nbytes, dtype=np.uint8) if nphd else None
     lo, hi = shard_range(args.rows, rank, world)
     table.add_synthetic(args.nbytes, hi - lo, SEED_CODES, first_row=lo, key_base=0)
     sharded = ShardedTable(HipShardOps(table, device), always_gather=args.force_collective)
@@ -123,7 +126,7 @@ def main():
     q, planted = make_queries(args.queries, args.rows, words)
 
     def step():
-        return sharded.search(q, None, args.k)
+        return sharded.search(q, q_nbytes, args.k)
 
     def fence():
         if world > 1:
@@ -187,7 +190,7 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.rows} x {args.nbytes * 8}-bit codes, brute-force Hamming k={args.k}, "
+            "workload": f"{args.rows} x {args.nbytes * 8}-bit codes, brute-force {'NPHD' if nphd else 'Hamming'} k={args.k}, "
                         f"{args.queries} queries/step in passes of T_q={args.tq}, rows sharded over {world} GPU(s)",
             "rows_total": args.rows,
             "rows_per_gpu": hi - lo,
