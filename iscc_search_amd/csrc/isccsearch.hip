@@ -27,6 +27,7 @@
 
 #include "../../include/isccsearch.h"
 #include "kernels.hip.h"
+#include "keymap.h"
 
 namespace {
 
@@ -50,21 +51,10 @@ int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                              \
     } while (0)
 
-struct Key {
-    uint64_t hi, lo;
-    bool operator==(const Key& o) const { return hi == o.hi && lo == o.lo; }
-};
-struct KeyHash {
-    size_t operator()(const Key& k) const {
-        uint64_t x = k.lo * 0x9E3779B97F4A7C15ULL ^ (k.hi + 0xBF58476D1CE4E5B9ULL + (k.lo << 6) + (k.lo >> 2));
-        x ^= x >> 32;
-        return (size_t)x;
-    }
-};
-struct Loc {
-    uint32_t seg;   // segment = code length in bytes
-    uint64_t row;
-};
+using iskhost::Key;
+using iskhost::KeyHash;
+using iskhost::KeyMap;
+using iskhost::Loc;
 
 struct Segment {
     uint32_t nbytes = 0, W = 0;
@@ -79,7 +69,7 @@ struct Table {
     int metric = 0, key_words = 1, max_bytes = 0, max_words = 0;
     Segment seg[ISCCSEARCH_MAX_BYTES + 1];
     bool indexed = false;
-    std::unordered_map<Key, Loc, KeyHash> index;
+    KeyMap index;
     uint64_t total = 0;
 };
 
@@ -234,7 +224,7 @@ int get_table(H* h, uint32_t id, Table*& out) {
 
 int ensure_index(H* h, Table& t) {
     if (t.indexed) return 0;
-    t.index.clear();
+    t.index.reset(t.key_words == 2);
     t.index.reserve((size_t)t.total + 16);
     for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
         Segment& s = t.seg[b];
@@ -244,7 +234,7 @@ int ensure_index(H* h, Table& t) {
         HIPOK(hipStreamSynchronize(h->stream));
         for (uint64_t r = 0; r < s.n; ++r) {
             Key k = t.key_words == 2 ? Key{s.hkeys[2 * r], s.hkeys[2 * r + 1]} : Key{0, s.hkeys[r]};
-            t.index[k] = Loc{b, r};
+            t.index.set(k, Loc{b, r});
         }
     }
     t.indexed = true;
@@ -820,7 +810,7 @@ int isccsearch_add(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
         seen.reserve((size_t)n);
         for (uint64_t i = 0; i < n; ++i) {
             Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
-            if (t.index.count(k) || !seen.emplace(k, 1).second)
+            if (t.index.contains(k) || !seen.emplace(k, 1).second)
                 return fail(-EEXIST, "key %016llx%016llx already present (row %llu of the batch)", (unsigned long long)k.hi, (unsigned long long)k.lo, (unsigned long long)i);
         }
     }
@@ -871,7 +861,7 @@ int isccsearch_add(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
             s.hkeys.insert(s.hkeys.end(), kp, kp + m * KW);
             for (uint64_t r = 0; r < m; ++r) {
                 Key k = KW == 2 ? Key{kp[2 * r], kp[2 * r + 1]} : Key{0, kp[r]};
-                t.index[k] = Loc{b, s.n + r};
+                t.index.set(k, Loc{b, s.n + r});
             }
         }
         s.n += m;
@@ -932,7 +922,7 @@ int isccsearch_add_columns(isccsearch_handle* h, uint32_t table, int nbytes, uin
         seen.reserve((size_t)n);
         for (uint64_t i = 0; i < n; ++i) {
             Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
-            if (t.index.count(k) || !seen.emplace(k, 1).second)
+            if (t.index.contains(k) || !seen.emplace(k, 1).second)
                 return fail(-EEXIST, "key %016llx%016llx already present (row %llu of the batch)", (unsigned long long)k.hi, (unsigned long long)k.lo, (unsigned long long)i);
         }
     }
@@ -946,7 +936,7 @@ int isccsearch_add_columns(isccsearch_handle* h, uint32_t table, int nbytes, uin
         s.hkeys.insert(s.hkeys.end(), keys, keys + n * KW);
         for (uint64_t r = 0; r < n; ++r) {
             Key k = KW == 2 ? Key{keys[2 * r], keys[2 * r + 1]} : Key{0, keys[r]};
-            t.index[k] = Loc{(uint32_t)nbytes, s.n + r};
+            t.index.set(k, Loc{(uint32_t)nbytes, s.n + r});
         }
     }
     s.n += n;
@@ -999,16 +989,15 @@ int isccsearch_remove(isccsearch_handle* h, uint32_t table, uint64_t n, const ui
     uint64_t removed = 0;
     for (uint64_t i = 0; i < n; ++i) {
         Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
-        auto it = t.index.find(k);
-        if (it == t.index.end()) continue;
-        const Loc loc = it->second;
+        Loc loc;
+        if (!t.index.find(k, loc)) continue;
         Segment& s = t.seg[loc.seg];
         const uint64_t last = s.n - 1;
-        t.index.erase(it);
+        t.index.erase(k);
         if (loc.row != last) {
             Key lk2 = KW == 2 ? Key{s.hkeys[2 * last], s.hkeys[2 * last + 1]} : Key{0, s.hkeys[last]};
             for (int w = 0; w < KW; ++w) s.hkeys[loc.row * KW + w] = s.hkeys[last * KW + w];
-            t.index[lk2] = Loc{loc.seg, loc.row};
+            t.index.set(lk2, Loc{loc.seg, loc.row});
             moves[loc.seg].push_back(loc.row);
             moves[loc.seg].push_back(last);
         }
@@ -1046,7 +1035,7 @@ int isccsearch_contains(isccsearch_handle* h, uint32_t table, uint64_t n, const 
     const int KW = tp->key_words;
     for (uint64_t i = 0; i < n; ++i) {
         Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
-        out_found[i] = tp->index.count(k) ? 1 : 0;
+        out_found[i] = tp->index.contains(k) ? 1 : 0;
     }
     return 0;
 }
@@ -1069,11 +1058,11 @@ int isccsearch_get(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
     std::vector<uint64_t> rows[ISCCSEARCH_MAX_BYTES + 1], dest[ISCCSEARCH_MAX_BYTES + 1];
     for (uint64_t i = 0; i < n; ++i) {
         Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
-        auto it = t.index.find(k);
-        if (it == t.index.end()) continue;
-        rows[it->second.seg].push_back(it->second.row);
-        dest[it->second.seg].push_back(i);
-        out_nbytes[i] = (uint8_t)it->second.seg;
+        Loc loc;
+        if (!t.index.find(k, loc)) continue;
+        rows[loc.seg].push_back(loc.row);
+        dest[loc.seg].push_back(i);
+        out_nbytes[i] = (uint8_t)loc.seg;
     }
     std::vector<uint64_t> tmp;
     for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
