@@ -5,10 +5,14 @@ Covers both metrics, both key widths, every code length 1..32 bytes, k from 1 to
 than one pipeline run (1 024 queries), all queries-per-pass settings, heavy ties and tiny tables.
 """
 
+import os
+
 import numpy as np
 import pytest
 
 from oracle_engine import OracleTable
+
+N_SEEDS = int(os.environ.get("ISCC_FUZZ_SEEDS", "12"))   # raise for a longer soak
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +38,7 @@ def _compare(got, exp, tag):
         np.testing.assert_array_equal(got[0][q, :c], exp[0][q, :c], err_msg=f"{tag}: keys q={q}")
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_operation_sequences(hip_engine, seed):
     rng = np.random.default_rng(1000 + seed)
     metric = int(rng.integers(0, 2))
