@@ -244,11 +244,16 @@ int ensure_index(H* h, Table& t) {
 // ------------------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------------------
+bool g_fold = false;  // experimental OR-fold filter for 64-bit codes (option "fold"; process-wide; off: see DESIGN.md section 4)
+
 template <int W, bool MASK, int TQ, int MODE>
 void launch_scan_nt(bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     // only the non-temporal variant is instantiated: plain loads measured no faster and
     // every extra variant costs build time
     (void)nt;
+    if constexpr (W == 1 && !MASK) {
+        if (g_fold) { hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true, true>), grid, dim3(isk::BLOCK), 0, st, p); return; }
+    }
     hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true>), grid, dim3(isk::BLOCK), 0, st, p);
 }
 template <int W, bool MASK, int TQ>
@@ -707,6 +712,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     }
     if (!strcmp(name, "profile")) { h->profile = value != 0; return 0; }
     if (!strcmp(name, "nontemporal")) { h->nontemporal = value != 0; return 0; }
+    if (!strcmp(name, "fold")) { g_fold = value != 0; return 0; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(-EINVAL, "blocks_per_cu must be 1..64"); h->blocks_per_cu = (uint32_t)value; return 0; }
     if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) { if (value < 1 || value > 10000) return fail(-EINVAL, "sample_cost must be 1..10000"); h->sample_cost = (uint64_t)value; return 0; }

@@ -177,8 +177,9 @@ __device__ __forceinline__ void emit(const ScanParams& p, uint32_t qi, uint32_t 
 //   so acc < 2^31  <=>  hamming <= tau_q, and one v_min3 folds two rows into the lane's running
 //   minimum.  Only lanes whose minimum has bit 31 clear enter the (rare) emit path.
 // ---------------------------------------------------------------------------------------------
-template <int W, bool MASK, int TQ, int MODE, bool NT>
+template <int W, bool MASK, int TQ, int MODE, bool NT, bool FOLD = false>
 __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
+    static_assert(!FOLD || (W == 1 && !MASK), "the OR-fold filter is for whole 64-bit codes");
     constexpr int U = TileCfg<W>::U;
     constexpr int TILE = BLOCK * 2 * U;
     const uint32_t tid = threadIdx.x;
@@ -224,6 +225,19 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t a0, a1;
+                if constexpr (FOLD) {
+                    // OR-fold filter for 64-bit codes: y = (lo ^ q_lo) | (hi ^ q_hi) has popc(y) <= hamming, so
+                    // popc(y) <= tau is NECESSARY for a candidate.  One v_xor + one v_bitop3 (a | (b ^ c)) + one
+                    // v_bcnt per row: 3.5 VALU ops per pair instead of 4.5.  For unrelated codes y is 3/4 ones
+                    // (popc ~ 24 +- 2.4), so at tau ~ 12-15 the filter passes ~1e-5 of the pairs; the exact
+                    // distance is computed in the emit path below.
+                    const uint32_t y0 = __builtin_amdgcn_bitop3_b32(v[u][0].x ^ qlo[q][0], v[u][0].y, qhi[q][0], 0xF6);
+                    const uint32_t y1 = __builtin_amdgcn_bitop3_b32(v[u][0].z ^ qlo[q][0], v[u][0].w, qhi[q][0], 0xF6);
+                    a0 = (uint32_t)__builtin_popcount(y0) + bias[q];   // one v_bcnt_u32_b32 with the SGPR bias as accumulator
+                    a1 = (uint32_t)__builtin_popcount(y1) + bias[q];
+                    m = min3u(m, a0, a1);
+                    continue;
+                }
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
                     uint32_t x0 = v[u][w].x ^ qlo[q][w], y0 = v[u][w].y ^ qhi[q][w];

@@ -18,6 +18,8 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t s0, 
                 if (OP == 1) { asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a[j]) : "s"(s1)); }
                 if (OP == 2) { asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(a[(j + 1) & 7])); }
                 if (OP == 3) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[j]) : "s"(s1)); }
+                if (OP == 5) { asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf6" : "+v"(a[j]) : "v"(a[(j + 1) & 7]), "s"(s0)); }
+                if (OP == 6) { asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(a[(j + 1) & 7]), "s"(s0)); }
                 if (OP == 4) { asm volatile("v_xor_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %0, %2" : "+v"(a[j]) : "s"(s0), "s"(s1)); }
             }
         }
@@ -57,6 +59,8 @@ int main() {
         run<2>("v_min3", 1, b);
         run<3>("v_add", 1, b);
         run<4>("xor+bcnt", 2, b);
+        run<5>("v_bitop3", 1, b);
+        run<6>("v_or3", 1, b);
     }
     return 0;
 }
