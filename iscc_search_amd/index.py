@@ -271,46 +271,48 @@ class HipIndex:
             asset = self.get_asset(query.iscc_id)
             query = IsccQuery(iscc_code=asset.iscc_code, units=asset.units, simprints=None)
         query = normalize_query(query)
-        with self._lock:
-            chunk_matches = []
-            if self._sp_tables and query.simprints:
-                chunk_matches = self._search_simprints(query, limit)
-            matches = []
-            if query.units:
-                aggregated = {}  # type: Dict[int, Dict[str, float]]
-                for unit_str in query.units:
-                    unit = codec.Iscc(unit_str)
-                    unit_type = unit.unit_type
-                    if unit_type.startswith("INSTANCE_"):
-                        for key, score in self._search_instance_unit(unit_type, unit.body).items():
-                            aggregated.setdefault(key, {})[unit_type] = score
-                    elif unit_type in self._unit_tables:
-                        for key, score in self._search_similarity_unit(unit_type, unit.body, limit).items():
-                            slot = aggregated.setdefault(key, {})
-                            slot[unit_type] = max(slot.get(unit_type, 0.0), score)
-                scored = []
-                thr, exp = self._opts.match_threshold_units, self._opts.confidence_exponent
-                for key, unit_scores in aggregated.items():
-                    confident = {t: s for t, s in unit_scores.items() if s >= thr}
-                    if not confident:
-                        continue
-                    weight_sum = sum(confident.values())
-                    total = sum(s**exp for s in confident.values()) / weight_sum if weight_sum > 0 else 0.0
-                    scored.append((key, total, unit_scores))
-                if query_iscc_id:
-                    qkey = codec.iscc_id_to_int(query_iscc_id)
-                    scored = [r for r in scored if r[0] != qkey]
-                scored.sort(key=lambda r: r[1], reverse=True)   # stable, as the reference (:836)
-                for key, total, unit_scores in scored[:limit]:
-                    asset = self._assets.get(key)
-                    source = metadata = None
-                    if asset is not None and asset.metadata:
-                        source = asset.metadata.get("source")
-                        metadata = asset.metadata
-                    matches.append(IsccGlobalMatch(
-                        iscc_id=codec.iscc_id_from_int(key, self._realm_id or 0), score=min(1.0, total),
-                        types=unit_scores, source=source, metadata=metadata,
-                    ))
+        # No index-wide lock here: the engine serialises (and combines) concurrent searches itself, the host
+        # dicts are only read, and writers (add_assets) publish whole entries -- as with the reference, a search
+        # that overlaps an add may or may not see that batch.
+        chunk_matches = []
+        if self._sp_tables and query.simprints:
+            chunk_matches = self._search_simprints(query, limit)
+        matches = []
+        if query.units:
+            aggregated = {}  # type: Dict[int, Dict[str, float]]
+            for unit_str in query.units:
+                unit = codec.Iscc(unit_str)
+                unit_type = unit.unit_type
+                if unit_type.startswith("INSTANCE_"):
+                    for key, score in self._search_instance_unit(unit_type, unit.body).items():
+                        aggregated.setdefault(key, {})[unit_type] = score
+                elif unit_type in self._unit_tables:
+                    for key, score in self._search_similarity_unit(unit_type, unit.body, limit).items():
+                        slot = aggregated.setdefault(key, {})
+                        slot[unit_type] = max(slot.get(unit_type, 0.0), score)
+            scored = []
+            thr, exp = self._opts.match_threshold_units, self._opts.confidence_exponent
+            for key, unit_scores in aggregated.items():
+                confident = {t: s for t, s in unit_scores.items() if s >= thr}
+                if not confident:
+                    continue
+                weight_sum = sum(confident.values())
+                total = sum(s**exp for s in confident.values()) / weight_sum if weight_sum > 0 else 0.0
+                scored.append((key, total, unit_scores))
+            if query_iscc_id:
+                qkey = codec.iscc_id_to_int(query_iscc_id)
+                scored = [r for r in scored if r[0] != qkey]
+            scored.sort(key=lambda r: r[1], reverse=True)   # stable, as the reference (:836)
+            for key, total, unit_scores in scored[:limit]:
+                asset = self._assets.get(key)
+                source = metadata = None
+                if asset is not None and asset.metadata:
+                    source = asset.metadata.get("source")
+                    metadata = asset.metadata
+                matches.append(IsccGlobalMatch(
+                    iscc_id=codec.iscc_id_from_int(key, self._realm_id or 0), score=min(1.0, total),
+                    types=unit_scores, source=source, metadata=metadata,
+                ))
         if query_iscc_id:
             chunk_matches = [m for m in chunk_matches if m.iscc_id != query_iscc_id]
         return IsccSearchResult(query=query, global_matches=matches, chunk_matches=chunk_matches)
