@@ -169,6 +169,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size_scan_tq8.json")) as f:
             pmc = json.load(f)
         if args.rows == 100_000_000 and args.nbytes == 8 and world == 1 and st["scan_launches"]:
+            # per-pass HBM bytes of the streaming scan for this exact workload (rows, k fix what the pass covers)
             traffic = pmc["corrected_bytes_per_pass"] * st["scan_passes"] / st["scan_launches"]
     except (OSError, KeyError, ValueError):
         traffic = None
