@@ -19,6 +19,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (gfx950) device")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build them once, as build() would."""
+    import subprocess
+
+    lib = os.path.join(ROOT, "iscc_search_amd", "csrc", "libisccsearch_hip.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "iscc_search_amd", "csrc")], check=True, capture_output=True)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+
+
 @pytest.fixture(scope="session")
 def hip_engine():
     """One engine for the whole GPU session (a single process on the card)."""
