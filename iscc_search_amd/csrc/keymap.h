@@ -12,10 +12,16 @@ struct Key {
     bool operator==(const Key& o) const { return hi == o.hi && lo == o.lo; }
 };
 struct KeyHash {
+    // Full avalanche on both words (splitmix64 finaliser).  Linear probing needs it: composite simprint keys are
+    // (small consecutive asset ids, a handful of offset|size values), which a multiply-xor hash maps to long runs
+    // of consecutive slots (a 4 M-key build took 35 s before this).
+    static uint64_t mix(uint64_t x) {
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+        x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+        return x ^ (x >> 31);
+    }
     size_t operator()(const Key& k) const {
-        uint64_t x = k.lo * 0x9E3779B97F4A7C15ULL ^ (k.hi + 0xBF58476D1CE4E5B9ULL + (k.lo << 6) + (k.lo >> 2));
-        x ^= x >> 32;
-        return (size_t)x;
+        return (size_t)mix(mix(k.lo + 0x9E3779B97F4A7C15ULL) ^ (k.hi * 0xD6E8FEB86659FD93ULL + 0x2545F4914F6CDD1DULL));
     }
 };
 struct Loc {

@@ -58,6 +58,19 @@ int main() {
         const bool f = m.find(Key{0, i * 2654435761ULL}, l);
         if (f != (i % 2 == 1) || (f && l.row != i)) { printf("bulk find mismatch at %llu\n", (unsigned long long)i); return 1; }
     }
+    // composite simprint keys: consecutive asset ids x few (offset|size) values; must stay fast (no clustering)
+    {
+        KeyMap w;
+        w.reset(true);
+        const uint64_t assets = 100000, chunks = 40;
+        w.reserve(assets * chunks);
+        for (uint64_t a = 1; a <= assets; ++a)
+            for (uint64_t c = 0; c < chunks; ++c) w.set(Key{a, (c * 100) << 32 | 100}, Loc{16, a * chunks + c});
+        if (w.size() != assets * chunks) { printf("composite size mismatch\n"); return 1; }
+        Loc l;
+        for (uint64_t a = 1; a <= assets; a += 997)
+            if (!w.find(Key{a, (7 * 100ULL) << 32 | 100}, l) || l.row != a * chunks + 7) { printf("composite find mismatch\n"); return 1; }
+    }
     printf("keymap ok\n");
     return 0;
 }

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""End-to-end timing of HipSimprintIndex.search_raw (config 5 shape): GPU search + host IDF scoring."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from iscc_search_amd.engine import HipEngine  # noqa: E402
+from iscc_search_amd.simprint import HipSimprintIndex, pack_chunk_pointer  # noqa: E402
+
+eng = HipEngine(0)
+rng = np.random.default_rng(0)
+n_assets, chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000, 40      # 4 M chunks
+ndim = 128
+idx = HipSimprintIndex(eng, ndim=ndim)
+t0 = time.perf_counter()
+bodies = (np.arange(n_assets, dtype=np.uint64) + np.uint64(1)).astype(">u8").view("V8")
+for a0 in range(0, n_assets, 10_000):
+    a1 = min(n_assets, a0 + 10_000)
+    vecs = rng.integers(0, 256, size=((a1 - a0) * chunks, ndim // 8), dtype=np.uint8)
+    keys = [pack_chunk_pointer(bytes(bodies[a]), c * 100, 100) for a in range(a0, a1) for c in range(chunks)]
+    idx.add_raw(keys, list(vecs))
+    if a0 == 0:
+        first = vecs[: chunks * 5].copy()
+print(f"ingest {idx.size} chunks: {time.perf_counter() - t0:.1f} s")
+for nq in (16, 64, 256):
+    # query = chunks of the first assets with a few bits flipped
+    q = first[:nq].copy()
+    q[:, 0] ^= 3
+    simprints = [bytes(r) for r in q]
+    for limit in (10,):
+        t0 = time.perf_counter()
+        res = idx.search_raw(simprints, limit=limit * 2, threshold=0.75, detailed=True, doc_freq_fn=lambda s: 1, total_assets=n_assets)
+        dt = time.perf_counter() - t0
+        print(f"search_raw nq={nq} limit={limit*2} (count={limit*2*20}): {dt*1e3:8.2f} ms, {len(res)} assets, top score {res[0].score:.4f}")
+eng.close()
