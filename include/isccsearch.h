@@ -133,6 +133,25 @@ int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const u
                       const uint8_t* q_nbytes, uint32_t k,
                       uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
 
+/* Range-limited exact k-NN: as isccsearch_search, but only rows whose Hamming distance over the compared
+ * prefix is <= max_hamming (0..256) are reported -- nearest first, ties by ascending key, at most k per query;
+ * out_count[q] may be 0.  One streaming pass at a fixed threshold (no sampling passes).
+ * max_hamming = 0 is the hard-boundary collision lookup the reference serves from its LMDB dupsort table
+ * (search_simprints_exact, iscc_search/indexes/simprint/lmdb_ops.py:169-249; called with exact=True from
+ * iscc_search/indexes/usearch/index.py:1261-1304): every row equal to the query, in ascending key order, which
+ * is the byte order LMDB iterates duplicate chunk pointers in; k plays the part of its dup_limit (:197-203).
+ * On an NPHD table the same call is the INSTANCE prefix match (usearch/index.py:1957-2022). */
+int isccsearch_search_within(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                             const uint8_t* q_nbytes, uint32_t k, uint32_t max_hamming,
+                             uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
+
+/* Document frequency of nq codes: out_freq[q] = number of DISTINCT assets among the first dup_limit rows
+ * (ascending key) that equal code q.  The asset is the first key word of a 2-word key (the ISCC-ID body of a
+ * chunk pointer, lmdb_ops.py:30-49); with 1-word keys every row is its own asset.
+ * Replaces count_doc_freq (lmdb_ops.py:139-166, called per matched simprint from usearch/index.py:1395-1403). */
+int isccsearch_doc_freq(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                        const uint8_t* q_nbytes, uint32_t dup_limit, uint32_t* out_freq);
+
 /* Multi-GPU building blocks (row-range shards, one process per GPU).
  * search_device: same search, results left in caller-provided DEVICE memory
  *   d_records[nq*k] (isccsearch_record), d_counts[nq]; queries must share one byte length.

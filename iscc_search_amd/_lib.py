@@ -25,7 +25,8 @@ EXPORTS = (
     "isccsearch_stats_get", "isccsearch_table_open", "isccsearch_table_drop", "isccsearch_reserve",
     "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
     "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
-    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_device", "isccsearch_merge_device",
+    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_doc_freq",
+    "isccsearch_search_device", "isccsearch_merge_device",
 )
 
 RECORD_DTYPE = np.dtype(
@@ -103,6 +104,8 @@ def load_library():
         "isccsearch_add_columns": (i, [vp, u32, i, u64, u64p, u64p, u32]),
         "isccsearch_add_synthetic": (i, [vp, u32, i, u64, u64, u64, u64]),
         "isccsearch_search": (i, [vp, u32, u32, u64p, u8p, u32, u64p, u32p, u16p, u32p]),
+        "isccsearch_search_within": (i, [vp, u32, u32, u64p, u8p, u32, u32, u64p, u32p, u16p, u32p]),
+        "isccsearch_doc_freq": (i, [vp, u32, u32, u64p, u8p, u32, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
         "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, u64p, u32p, u16p, u32p]),
     }

@@ -143,7 +143,7 @@ struct isccsearch_handle {
     uint16_t* d_rank = nullptr;
     // scratch
     DevBuf<uint64_t> d_queries;     // [nq_pad][4]
-    DevBuf<uint32_t> d_bias, d_cnt, d_ghist, d_overflow, d_listcnt, d_outcnt;
+    DevBuf<uint32_t> d_bias, d_cnt, d_ghist, d_overflow, d_listcnt, d_outcnt, d_freq;
     DevBuf<uint64_t> d_cand;
     DevBuf<isk::Record> d_lists, d_final;
     PinBuf<uint64_t> p_queries;     // pinned staging: queries in, flags / results out
@@ -350,6 +350,7 @@ struct Batch {
     isk::Record* d_out;       // [nq*k]   device
     uint32_t* d_out_cnt;      // [nq]     device
     int tq = 8;
+    int radius = -1;          // >= 0: report only rows within this Hamming distance (fixed threshold, no sampling)
     uint32_t nq_pad = 0, groups = 0, cap = 0, P = 0;
     size_t sel_lds = 0;
     bool multi = false;
@@ -429,6 +430,26 @@ struct Batch {
             Segment& s = *j.seg;
             Ctx c = make_ctx(ji);
             isk::ScanParams& sp = c.sp;
+
+            if (radius >= 0) {
+                // range-limited search: the threshold is given, so one streaming pass collects everything
+                HIPOK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_bias.p), (int)(0x7FFFFFFFu - (uint32_t)radius), nq, h->stream));
+                if (nq_pad > nq)
+                    HIPOK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_bias.p + nq), (int)isk::BIAS_NEVER, nq_pad - nq, h->stream));
+                HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
+                sp.row_begin = 0;
+                sp.n_rows = s.n;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
+                launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n, groups), groups), h->stream, sp);
+                if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+                h->stats.scan_launches += 1;
+                h->stats.scan_passes += groups;
+                h->stats.scan_bytes += s.n * 8 * j.W * groups;
+                launch_select(c.sl, nq);
+                HIPOK(hipGetLastError());
+                continue;
+            }
 
             // 1. bootstrap threshold from the first s0 rows
             const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
@@ -525,7 +546,17 @@ struct Batch {
                 HIPOK(hipStreamSynchronize(h->stream));
                 uint64_t cum = 0, less = 0;
                 uint32_t tau = 256;
-                const uint64_t need = std::min<uint64_t>(k, s.n);
+                uint64_t within = s.n;               // rows a range-limited search may report at all
+                if (radius >= 0) {
+                    within = 0;
+                    for (uint32_t b = 0; b < isk::NBINS && b <= (uint32_t)radius; ++b) within += fh[b];
+                }
+                const uint64_t need = std::min<uint64_t>(std::min<uint64_t>(k, s.n), within);
+                if (need == 0) {
+                    HIPOK(hipMemsetAsync(c.sl.out_count + q, 0, sizeof(uint32_t), h->stream));
+                    HIPOK(hipMemsetAsync(c.sl.overflow + q, 0, sizeof(uint32_t), h->stream));
+                    continue;
+                }
                 for (uint32_t b = 0; b < isk::NBINS; ++b) { less = cum; cum += fh[b]; if (cum >= need) { tau = b; break; } }
                 // `less` rows lie strictly below tau, `cum - less` rows tie at tau.  When the tie class is too
                 // large to collect, pin down the r = need - less smallest KEYS of it by radix select over
@@ -688,7 +719,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         for (auto& t : h->tables)
             if (t) for (auto& s : t->seg) seg_free(s);
         h->tables.clear();
-        h->d_queries.release(); h->d_bias.release(); h->d_cnt.release(); h->d_ghist.release();
+        h->d_queries.release(); h->d_bias.release(); h->d_cnt.release(); h->d_ghist.release(); h->d_freq.release();
         h->d_overflow.release(); h->d_listcnt.release(); h->d_outcnt.release(); h->d_cand.release();
         h->d_lists.release(); h->d_final.release(); h->d_misc.release(); h->d_misc2.release();
         h->p_queries.release(); h->p_flags.release(); h->p_cnt.release(); h->p_final.release();
@@ -1094,9 +1125,12 @@ int isccsearch_get(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
 }
 
 // The search itself; h->mu is held by the caller.
+//   radius >= 0   range-limited search (fixed threshold)
+//   out_freq      when set, only the number of distinct assets per result list is returned (doc frequency)
 static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                          const uint8_t* q_nbytes, uint32_t k,
-                         uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+                         uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count,
+                         int radius = -1, uint32_t* out_freq = nullptr) {
     Table* tp;
     int rc = get_table(h, table, tp);
     if (rc) return rc;
@@ -1127,7 +1161,18 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         if ((rc = h->p_final.ensure((size_t)m * k))) return rc;
         if ((rc = h->p_cnt.ensure(m))) return rc;
         Batch batch(h, t, m, len, k, h->d_final.p, h->d_outcnt.p);
+        batch.radius = radius;
         auto copy_results = [&]() -> int {
+            if (out_freq) {
+                // only the distinct-asset count of every list leaves the device
+                int rf;
+                if ((rf = h->d_freq.ensure(m))) return rf;
+                isk::DistinctParams dp{h->d_final.p, h->d_outcnt.p, h->d_freq.p, k, (uint32_t)t.key_words};
+                hipLaunchKernelGGL(isk::distinct_kernel, dim3(m), dim3(isk::BLOCK), 0, h->stream, dp);
+                HIPOK(hipGetLastError());
+                HIPOK(hipMemcpyAsync(h->p_cnt.p, h->d_freq.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                return 0;
+            }
             HIPOK(hipMemcpyAsync(h->p_final.p, h->d_final.p, (size_t)m * k * sizeof(isk::Record), hipMemcpyDeviceToHost, h->stream));
             HIPOK(hipMemcpyAsync(h->p_cnt.p, h->d_outcnt.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
             return 0;
@@ -1152,7 +1197,12 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 HIPOK(hipStreamSynchronize(h->stream));
             }
         }
-        unpack_records(h->p_final.p, h->p_cnt.p, m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
+        if (out_freq) {
+            if (batch.jobs.empty()) for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = 0;
+            else for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = h->p_cnt.p[i];
+        } else {
+            unpack_records(h->p_final.p, h->p_cnt.p, m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
+        }
         pos = end;
     }
     return 0;
@@ -1278,6 +1328,31 @@ int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const u
     h->qcv.notify_all();
     if (me.rc) g_last_error = me.err;
     return me.rc;
+}
+
+int isccsearch_search_within(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                             const uint8_t* q_nbytes, uint32_t k, uint32_t max_hamming,
+                             uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (k < 1) return fail(-EINVAL, "`count` must be >= 1");
+    if (k > ISCCSEARCH_MAX_K) return fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", k, ISCCSEARCH_MAX_K);
+    if (max_hamming > 256) return fail(-EINVAL, "max_hamming %u exceeds 256", max_hamming);
+    if (nq == 0) return 0;
+    if (!q_words || !out_keys || !out_hamming || !out_prefix_bits || !out_count) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->stats.searches += 1;
+    return search_locked(h, table, nq, q_words, q_nbytes, k, out_keys, out_hamming, out_prefix_bits, out_count, (int)max_hamming);
+}
+
+int isccsearch_doc_freq(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                        const uint8_t* q_nbytes, uint32_t dup_limit, uint32_t* out_freq) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (dup_limit < 1 || dup_limit > ISCCSEARCH_MAX_K) return fail(-EINVAL, "dup_limit %u outside 1..ISCCSEARCH_MAX_K (%d)", dup_limit, ISCCSEARCH_MAX_K);
+    if (nq == 0) return 0;
+    if (!q_words || !out_freq) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->stats.searches += 1;
+    return search_locked(h, table, nq, q_words, q_nbytes, dup_limit, nullptr, nullptr, nullptr, nullptr, 0, out_freq);
 }
 
 int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,

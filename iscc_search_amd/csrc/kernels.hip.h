@@ -582,13 +582,16 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
     }
     __syncthreads();
     const uint32_t got = n_out < P ? n_out : P;     // == keff when keys are unique
-    for (uint32_t i = got + tid; i < P; i += BLOCK) { sh[i] = 0xFFFFFFFFu; sklo[i] = ~0ULL; if (KW == 2) skhi[i] = ~0ULL; }
+    // sort only as many slots as hold winners (a range-limited search asks for a large k and finds few rows)
+    uint32_t Ps = 1;
+    while (Ps < got) Ps <<= 1;
+    for (uint32_t i = got + tid; i < Ps; i += BLOCK) { sh[i] = 0xFFFFFFFFu; sklo[i] = ~0ULL; if (KW == 2) skhi[i] = ~0ULL; }
     __syncthreads();
 
     // bitonic sort ascending by (h, khi, klo)
-    for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t size = 2; size <= Ps; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t i = tid; i < (P >> 1); i += BLOCK) {
+            for (uint32_t i = tid; i < (Ps >> 1); i += BLOCK) {
                 const uint32_t lo_i = 2 * i - (i & (stride - 1));
                 const uint32_t hi_i = lo_i + stride;
                 const bool up = (lo_i & size) == 0;
@@ -769,6 +772,32 @@ __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams p) {
         if (rank < keff) p.out[(uint64_t)q * p.k + rank] = me;
     }
     if (tid == 0) p.out_count[q] = keff;
+}
+
+// ---------------------------------------------------------------------------------------------
+// document frequency: distinct assets in one query's collision list.  The list is ordered by key, so
+// the rows of one asset (= first key word of a 2-word key) are adjacent: count the boundaries.
+// ---------------------------------------------------------------------------------------------
+struct DistinctParams {
+    const Record* rec;        // [nq][k] ascending (dist_rank, key)
+    const uint32_t* count;    // [nq]
+    uint32_t* out;            // [nq]
+    uint32_t k, KW;
+};
+__global__ __launch_bounds__(BLOCK) void distinct_kernel(const DistinctParams p) {
+    __shared__ uint32_t total;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    const uint32_t n = p.count[q] < p.k ? p.count[q] : p.k;
+    const Record* r = p.rec + (uint64_t)q * p.k;
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < n; i += BLOCK)
+        mine += (i == 0 || p.KW == 1 || r[i].key_hi != r[i - 1].key_hi) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((tid & 63) == 0 && mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (tid == 0) p.out[q] = total;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -260,6 +260,48 @@ class HipTable:
             )
         return out
 
+    def search_within(self, q_words, q_nbytes, k, max_hamming):
+        # type: (np.ndarray, np.ndarray | None, int, int) -> tuple
+        """
+        Range-limited exact top-k: only rows within ``max_hamming`` bits over the compared prefix, nearest
+        first, ties by ascending key.  ``max_hamming=0`` is the collision lookup of the reference's LMDB
+        dupsort path (``lmdb_ops.py:169-249``).  Same return shape as ``search``; counts may be 0.
+        """
+        q_words = self._words(q_words)
+        nq = q_words.shape[0]
+        if k < 1:
+            raise ValueError("`count` must be >= 1")
+        q_nbytes = self._nbytes(q_nbytes, nq)
+        out = _alloc_out(nq, k, self.key_words)
+        if nq:
+            _lib.check(
+                self.engine._lib.isccsearch_search_within(
+                    self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k,
+                    int(max_hamming), _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32),
+                    _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32),
+                )
+            )
+        return out
+
+    def doc_freq(self, q_words, q_nbytes=None, dup_limit=1000):
+        # type: (np.ndarray, np.ndarray | None, int) -> np.ndarray
+        """
+        Distinct assets (first key word) among the first ``dup_limit`` rows equal to each code
+        (``count_doc_freq``, ``lmdb_ops.py:139-166``) -> uint32 [nq].
+        """
+        q_words = self._words(q_words)
+        nq = q_words.shape[0]
+        q_nbytes = self._nbytes(q_nbytes, nq)
+        out = np.zeros(nq, dtype=np.uint32)
+        if nq:
+            _lib.check(
+                self.engine._lib.isccsearch_doc_freq(
+                    self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8),
+                    int(dup_limit), _lib.ptr(out, ctypes.c_uint32),
+                )
+            )
+        return out
+
     def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr):
         # type: (np.ndarray, np.ndarray | None, int, int, int) -> None
         """Same search, results left in caller-owned device memory (multi-GPU exchange)."""

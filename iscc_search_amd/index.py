@@ -249,22 +249,18 @@ class HipIndex:
         # type: (str, bytes) -> Dict[int, float]
         """
         Bidirectional prefix match of identity codes, every hit scoring 1.0 (``usearch/index.py:1957-2022``).
-        A stored code is a hit iff it agrees with the query on their common prefix, i.e. NPHD == 0:
-        the same GPU scan answers it.  Capped at MAX_K hits per query.
+        A stored code is a hit iff it agrees with the query on their common prefix, i.e. Hamming distance 0
+        over the compared prefix: one range-limited GPU scan answers it.  Capped at MAX_K hits per query.
         """
         table = self._unit_tables.get(unit_type)
         if table is None:
             return {}
-        k = 64
-        while True:
-            m = table.search(np.frombuffer(body, dtype=np.uint8), count=k)
-            zero = [int(key) for key, h in zip(m.keys, m.hamming) if h == 0]
-            if len(zero) < len(m) or len(m) < k or k >= MAX_K:
-                return {key: 1.0 for key in zero}
-            k = min(MAX_K, k * 8)
+        m = table.search_within(np.frombuffer(body, dtype=np.uint8), count=MAX_K, max_hamming=0)
+        return {int(key): 1.0 for key in m.keys}
 
-    def search_assets(self, query, limit=100):
-        # type: (IsccQuery, int) -> IsccSearchResult
+    def search_assets(self, query, limit=100, exact=False):
+        # type: (IsccQuery, int, bool) -> IsccSearchResult
+        """``exact=True`` matches simprints by collision only (``usearch/index.py:735-778, :1261-1304``)."""
         query_iscc_id = None
         if query.iscc_id:
             query_iscc_id = query.iscc_id
@@ -276,7 +272,7 @@ class HipIndex:
         # that overlaps an add may or may not see that batch.
         chunk_matches = []
         if self._sp_tables and query.simprints:
-            chunk_matches = self._search_simprints(query, limit)
+            chunk_matches = self._search_simprints(query, limit, exact=exact)
         matches = []
         if query.units:
             aggregated = {}  # type: Dict[int, Dict[str, float]]
@@ -317,9 +313,12 @@ class HipIndex:
             chunk_matches = [m for m in chunk_matches if m.iscc_id != query_iscc_id]
         return IsccSearchResult(query=query, global_matches=matches, chunk_matches=chunk_matches)
 
-    def _search_simprints(self, query, limit):
-        # type: (IsccQuery, int) -> List[IsccChunkMatch]
-        """Per-type search, mean over types, order (-score, iscc_id) (``usearch/index.py:1357-1469``)."""
+    def _search_simprints(self, query, limit, exact=False):
+        # type: (IsccQuery, int, bool) -> List[IsccChunkMatch]
+        """
+        Per-type search, mean over types, order (-score, iscc_id): approximate-mode scoring of
+        ``usearch/index.py:1357-1469``, or with ``exact`` the hard-boundary collision search of ``:1261-1355``.
+        """
         total_assets = len(self._assets)
         per_asset = {}  # type: Dict[bytes, Dict[str, object]]
         for sp_type, simprint_objs in query.simprints.items():
@@ -327,10 +326,13 @@ class HipIndex:
             if table is None:
                 continue
             q_bytes = [codec.decode_base64(_sp_string(s)) for s in simprint_objs]
-            raw = table.search_raw(
-                simprints=q_bytes, limit=limit * 2, threshold=self._opts.match_threshold_simprints, detailed=True,
-                doc_freq_fn=lambda sp, _t=sp_type: self._doc_freq(_t, sp), total_assets=total_assets,
-            )
+            if exact:
+                raw = table.search_exact(simprints=q_bytes, limit=limit * 2, threshold=self._opts.match_threshold_simprints, detailed=True)
+            else:
+                raw = table.search_raw(
+                    simprints=q_bytes, limit=limit * 2, threshold=self._opts.match_threshold_simprints, detailed=True,
+                    doc_freq_fn=lambda sp, _t=sp_type: self._doc_freq(_t, sp), total_assets=total_assets,
+                )
             for r in raw:
                 per_asset.setdefault(r.iscc_id_body, {})[sp_type] = r
         if not per_asset:

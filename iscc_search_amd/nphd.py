@@ -134,6 +134,18 @@ class HipNphdIndex:
         Exact ``count`` nearest rows.  One vector (1-D array / bytes) returns ``Matches``; a list of
         vectors or a 2-D array returns ``BatchMatches``.  ``distances`` are float32 NPHD values.
         """
+        return self._search(vectors, count, None)
+
+    def search_within(self, vectors, count, max_hamming=0):
+        # type: (object, int, int) -> Matches | BatchMatches
+        """
+        As ``search`` but only rows whose Hamming distance over the compared prefix is <= ``max_hamming``
+        (one streaming pass at a fixed threshold).  ``max_hamming=0`` is the prefix-equality match the
+        reference runs for INSTANCE units (``usearch/index.py:1957-2022``).
+        """
+        return self._search(vectors, count, int(max_hamming))
+
+    def _search(self, vectors, count, max_hamming):
         if count < 1:
             raise ValueError("`count` must be >= 1")
         single = isinstance(vectors, (bytes, bytearray)) or (isinstance(vectors, np.ndarray) and vectors.ndim == 1)
@@ -144,7 +156,10 @@ class HipNphdIndex:
         else:
             codes = [_as_bytes(v) for v in vectors]
         q_words, q_nbytes = pack_bytes(codes, self._table.max_words)
-        keys, ham, pbits, cnt = self._table.search(q_words, q_nbytes, count)
+        if max_hamming is None:
+            keys, ham, pbits, cnt = self._table.search(q_words, q_nbytes, count)
+        else:
+            keys, ham, pbits, cnt = self._table.search_within(q_words, q_nbytes, count, max_hamming)
         out = []
         for q in range(q_words.shape[0]):
             c = int(cnt[q])
@@ -338,6 +353,32 @@ class HipIndex128:
             c = int(cnt[q])
             out.append(Matches(words_to_key128(keys[q, :c]), ham[q, :c].astype(np.float32), ham[q, :c].copy(), pbits[q, :c].copy()))
         return out[0] if single else BatchMatches(out)
+
+    def search_within(self, vectors, count, max_hamming=0):
+        # type: (np.ndarray, int, int) -> Matches | BatchMatches
+        """
+        Only the rows within ``max_hamming`` bits, nearest first, ties by ascending key, at most ``count``.
+        ``max_hamming=0`` lists the collisions of each query in the order LMDB iterates the duplicates of a
+        simprint key (``lmdb_ops.py:197-203``).
+        """
+        if count < 1:
+            raise ValueError("`count` must be >= 1")
+        single = isinstance(vectors, np.ndarray) and vectors.ndim == 1
+        arr = self._vectors(vectors)
+        q_words, _ = pack_bytes(arr, self._table.max_words)
+        keys, ham, pbits, cnt = self._table.search_within(q_words, None, count, max_hamming)
+        out = []
+        for q in range(arr.shape[0]):
+            c = int(cnt[q])
+            out.append(Matches(words_to_key128(keys[q, :c]), ham[q, :c].astype(np.float32), ham[q, :c].copy(), pbits[q, :c].copy()))
+        return out[0] if single else BatchMatches(out)
+
+    def doc_freq(self, vectors, dup_limit=1000):
+        # type: (np.ndarray, int) -> np.ndarray
+        """Distinct assets (key[:8]) among the first ``dup_limit`` rows equal to each vector (``lmdb_ops.py:139-166``)."""
+        arr = self._vectors(vectors)
+        q_words, _ = pack_bytes(arr, self._table.max_words)
+        return self._table.doc_freq(q_words, None, dup_limit)
 
     def save(self, path):
         # type: (str) -> None

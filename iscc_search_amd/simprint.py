@@ -52,6 +52,26 @@ def calculate_idf(freq, total_assets):
     return math.log(1 + total_assets / (1 + freq))
 
 
+def coverage_quality_score(matched_simprints, doc_freq, queried):
+    # type: (list[bytes], dict[bytes, int], int) -> float
+    """
+    Coverage x quality of one asset's collisions (``lmdb_ops._calculate_coverage_quality_score``, :252-301).
+
+    coverage = distinct query simprints matched / simprints queried; quality = mean over those simprints of
+    the min-max normalised inverse document frequency (1.0 when there is one simprint or all frequencies agree).
+    """
+    if not matched_simprints:
+        return 0.0
+    freqs = [doc_freq.get(sp, 1) for sp in dict.fromkeys(matched_simprints)]
+    coverage = len(freqs) / queried
+    lo, hi = min(freqs), max(freqs)
+    if len(freqs) == 1 or lo == hi:
+        return coverage * 1.0
+    min_inv, max_inv = 1.0 / hi, 1.0 / lo
+    quality = sum((1.0 / f - min_inv) / (max_inv - min_inv) for f in freqs) / len(freqs)
+    return coverage * quality
+
+
 @dataclass
 class MatchedChunkRaw:
     query: bytes
@@ -170,6 +190,71 @@ class HipSimprintIndex:
             results.append(SimprintMatchRaw(iscc_id_body=asset_id, score=asset_score, queried=len(simprints), matches=len(best), chunks=chunks))
         results.sort(key=lambda r: (-r.score, r.iscc_id_body))
         return results[:limit]
+
+    def search_exact(self, simprints, limit=10, threshold=0.0, detailed=False, dup_limit=1000):
+        # type: (list[bytes], int, float, bool, int) -> list[SimprintMatchRaw]
+        """
+        Hard-boundary search: only stored simprints EQUAL to a query simprint match; assets are scored by
+        coverage x quality (``lmdb_ops.search_simprints_exact``, ``lmdb_ops.py:169-249``).
+
+        The reference walks the LMDB duplicates of each simprint key (at most ``dup_limit``, in chunk-pointer
+        byte order); here one range-limited scan with ``max_hamming=0`` lists the same rows in the same
+        order for all distinct query simprints at once.
+        """
+        if not simprints or len(self._index) == 0:
+            return []
+        nbytes = self.ndim // 8
+        distinct = [sp for sp in dict.fromkeys(bytes(s) for s in simprints) if len(sp) == nbytes]
+        hits = {}
+        if distinct:
+            queries = np.stack([np.frombuffer(sp, dtype=np.uint8) for sp in distinct])
+            batch = self._index.search_within(queries, count=min(MAX_K, max(1, dup_limit)), max_hamming=0)
+            hits = {sp: batch[i].keys for i, sp in enumerate(distinct)}
+
+        asset_matches = defaultdict(list)   # asset body -> [(query simprint, offset, size)]
+        doc_freq = {}
+        for sp in simprints:                # as given: a repeated query simprint is matched again (:197)
+            sp = bytes(sp)
+            keys = hits.get(sp)
+            if keys is None or len(keys) == 0:
+                continue
+            assets = set()
+            for raw_key in keys:
+                body = raw_key[:8]
+                offset, size = struct.unpack("!II", raw_key[8:16])
+                asset_matches[body].append((sp, offset, size))
+                assets.add(body)
+            doc_freq[sp] = len(assets)
+
+        queried = len(simprints)
+        results = []
+        for body, matches in asset_matches.items():
+            score = coverage_quality_score([m[0] for m in matches], doc_freq, queried)
+            if score < threshold:
+                continue
+            chunks = None
+            if detailed:
+                chunks = [MatchedChunkRaw(query=sp, match=sp, score=1.0, offset=offset, size=size, freq=doc_freq.get(sp, 1))
+                          for sp, offset, size in matches]
+            results.append(SimprintMatchRaw(iscc_id_body=body, score=score, queried=queried, matches=len(matches), chunks=chunks))
+        results.sort(key=lambda r: (-r.score, r.iscc_id_body))
+        return results[:limit]
+
+    def doc_freq(self, simprints, dup_limit=1000):
+        # type: (list[bytes], int) -> list[int]
+        """Distinct assets holding each simprint, counted on the device (``lmdb_ops.count_doc_freq``, :139-166)."""
+        if not simprints:
+            return []
+        if len(self._index) == 0:
+            return [0] * len(simprints)
+        nbytes = self.ndim // 8
+        ok = [i for i, sp in enumerate(simprints) if len(sp) == nbytes]
+        out = [0] * len(simprints)
+        if ok:
+            freq = self._index.doc_freq(np.stack([np.frombuffer(bytes(simprints[i]), dtype=np.uint8) for i in ok]), dup_limit)
+            for i, f in zip(ok, freq):
+                out[i] = int(f)
+        return out
 
     def save(self, path):
         # type: (str) -> None

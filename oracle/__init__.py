@@ -17,4 +17,4 @@ Two independent implementations are kept so they can check each other:
 """
 
 from oracle.clib import load_oracle, oracle_topk, oracle_splitmix64_fill, oracle_num_threads  # noqa: F401
-from oracle.nphd_ref import pack_codes, ref_topk, ref_distance_pairs  # noqa: F401
+from oracle.nphd_ref import pack_codes, ref_topk, ref_distance_pairs, ref_within, ref_doc_freq, np_within  # noqa: F401

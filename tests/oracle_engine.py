@@ -8,7 +8,7 @@ route through ``oracle/``; the product path has no such engine.
 
 import numpy as np
 
-from oracle import oracle_topk
+from oracle import np_within, oracle_topk
 
 RECORD_DTYPE = np.dtype(
     [("key_hi", "<u8"), ("key_lo", "<u8"), ("dist_rank", "<u4"), ("hamming", "<u2"), ("prefix_bits", "<u2")]
@@ -101,6 +101,32 @@ class OracleTable:
             shape = (nq, k, 2) if self.key_words == 2 else (nq, k)
             return np.zeros(shape, np.uint64), np.zeros((nq, k), np.uint32), np.zeros((nq, k), np.uint16), np.zeros(nq, np.uint32)
         return oracle_topk(1, keys, words, nb, q_words, np.asarray(q_nbytes, dtype=np.uint8), k)
+
+    def search_within(self, q_words, q_nbytes, k, max_hamming):
+        """Range-limited top-k by the vectorised numpy restatement (``oracle.np_within``)."""
+        if k < 1:
+            raise ValueError("`count` must be >= 1")
+        q_words = np.asarray(q_words, dtype=np.uint64).reshape(-1, self.max_words)
+        nq = q_words.shape[0]
+        kshape = (nq, k, 2) if self.key_words == 2 else (nq, k)
+        out = (np.zeros(kshape, np.uint64), np.zeros((nq, k), np.uint32), np.zeros((nq, k), np.uint16), np.zeros(nq, np.uint32))
+        if not self._rows:
+            return out
+        keys, words, nb = self._arrays()
+        for q in range(nq):
+            qb = self.max_bytes if self.metric == 0 else int(q_nbytes[q])
+            kk, h, p = np_within(words, nb, keys, q_words[q], qb, k, max_hamming)
+            c = len(h)
+            out[0][q, :c], out[1][q, :c], out[2][q, :c], out[3][q] = kk, h, p, c
+        return out
+
+    def doc_freq(self, q_words, q_nbytes=None, dup_limit=1000):
+        keys, _, _, cnt = self.search_within(q_words, q_nbytes, dup_limit, 0)
+        out = np.zeros(len(cnt), dtype=np.uint32)
+        for q, c in enumerate(cnt):
+            assets = keys[q, :c, 0] if self.key_words == 2 else keys[q, :c]
+            out[q] = len(np.unique(assets))
+        return out
 
     def search_records(self, q_words, q_nbytes, k):
         """Structured records [nq, k] + counts, as the device exchange format."""

@@ -1,0 +1,121 @@
+"""
+GPU parity of the range-limited search (``isccsearch_search_within``) and the document frequency
+(``isccsearch_doc_freq``) against the numpy restatement ``oracle.np_within`` -- bit-exact keys, Hamming
+distances, prefix lengths and counts, through the C-ABI.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import np_within
+from test_gpu_parity import METRIC_HAMMING, METRIC_NPHD, _mask_to_len, _rand_words
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_within(table, keys, words, nbytes, q_words, q_nbytes, k, r):
+    got = table.search_within(q_words, q_nbytes, k, r)
+    for q in range(q_words.shape[0]):
+        qb = table.max_bytes if q_nbytes is None else int(q_nbytes[q])
+        ek, eh, ep = np_within(words, table.max_bytes if nbytes is None else nbytes, keys, q_words[q], qb, k, r)
+        c = len(eh)
+        assert int(got[3][q]) == c, f"count q={q} r={r}: {int(got[3][q])} != {c}"
+        np.testing.assert_array_equal(got[1][q, :c], eh, err_msg=f"hamming q={q} r={r}")
+        np.testing.assert_array_equal(got[2][q, :c], ep, err_msg=f"prefix bits q={q} r={r}")
+        np.testing.assert_array_equal(got[0][q, :c], ek, err_msg=f"keys q={q} r={r}")
+        assert not got[0][q, c:].any() and not got[1][q, c:].any()
+
+
+@pytest.mark.parametrize("nbytes,key_words", [(8, 1), (8, 2), (16, 2), (32, 2), (13, 1)])
+def test_within_fixed_length_vs_numpy(hip_engine, nbytes, key_words):
+    """Planted collisions and near-collisions among random rows; radii from 0 up to 'most of the table'."""
+    rng = np.random.default_rng(100 + nbytes + key_words)
+    n, nq = 40000, 11
+    t = hip_engine.open_table(METRIC_HAMMING, key_words, nbytes)
+    try:
+        mw = t.max_words
+        words = _rand_words(rng, n, mw, nbytes)
+        pool = _rand_words(rng, 6, mw, nbytes)
+        for i in range(0, n, 7):                       # every 7th row is one of six codes ...
+            words[i] = pool[int(rng.integers(0, 6))]
+            if i % 3 == 0:                             # ... a third of them one or two bits away
+                words[i, 0] ^= np.uint64(1) << np.uint64(int(rng.integers(56, 64)))
+        if key_words == 2:
+            keys = np.stack([rng.integers(1, 300, size=n).astype(np.uint64), rng.permutation(n).astype(np.uint64)], axis=1)
+        else:
+            keys = rng.permutation(np.arange(n, dtype=np.uint64) * np.uint64(977) + np.uint64(3))
+        t.add(keys, words)
+        q = np.concatenate([pool, _rand_words(rng, nq - 6, mw, nbytes)])
+        for r, k in [(0, 1000), (0, 50), (1, 4096), (2, 300), (8 * nbytes // 4, 64)]:
+            _check_within(t, keys, words, None, q, None, k, r)
+        # document frequency = distinct first key words among the first dup_limit collisions
+        for dup_limit in (1000, 37):
+            freq = t.doc_freq(q, None, dup_limit)
+            for qi in range(q.shape[0]):
+                ek, _, _ = np_within(words, nbytes, keys, q[qi], nbytes, dup_limit, 0)
+                want = len(np.unique(ek[:, 0])) if key_words == 2 else len(ek)
+                assert int(freq[qi]) == want, (qi, dup_limit)
+    finally:
+        t.drop()
+
+
+def test_within_radius_beyond_the_candidate_buffer_takes_the_exact_fallback(hip_engine):
+    """A radius that admits most of the table overflows the candidate lists: the fallback must still
+    return the k nearest rows WITHIN the radius -- and nothing when the radius admits nothing."""
+    rng = np.random.default_rng(9)
+    n = 200000
+    t = hip_engine.open_table(METRIC_HAMMING, 1, 8)
+    try:
+        words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+        words[: n // 2] = np.uint64(0x0F0F0F0F0F0F0F0F)            # 100 000 equal rows
+        keys = rng.permutation(np.arange(n, dtype=np.uint64) + np.uint64(1))
+        t.add(keys, words)
+        q = np.array([[0x0F0F0F0F0F0F0F0F], [0x0F0F0F0F0F0F0F0E], [0xF0F0F0F0F0F0F0F0], [0x123456789ABCDEF0]], dtype=np.uint64)
+        before = hip_engine.stats()["fallback_queries"]
+        for r, k in [(0, 1000), (1, 10), (40, 100), (64, 4096)]:
+            _check_within(t, keys, words, None, q, None, k, r)
+        assert hip_engine.stats()["fallback_queries"] > before
+    finally:
+        t.drop()
+
+
+def test_within_nphd_mixed_lengths_is_the_prefix_match(hip_engine):
+    """NPHD table: radius 0 = bidirectional prefix equality (INSTANCE matching, usearch/index.py:1957-2022)."""
+    rng = np.random.default_rng(21)
+    n = 30000
+    t = hip_engine.open_table(METRIC_NPHD, 1, 32)
+    try:
+        lens = rng.choice([8, 16, 32, 12], size=n, p=[0.4, 0.3, 0.2, 0.1]).astype(np.uint8)
+        words = _rand_words(rng, n, 4, lens)
+        base = _rand_words(rng, 3, 4, 32)
+        for i in range(0, n, 11):                       # families of codes sharing a prefix at every length
+            words[i] = _mask_to_len(base[i % 3: i % 3 + 1], lens[i: i + 1])[0]
+            if i % 5 == 0:
+                words[i, 0] ^= np.uint64(1)             # differs in bit 63 of word 0 (inside every prefix)
+        keys = rng.permutation(np.arange(n, dtype=np.uint64) + np.uint64(1))
+        t.add(keys, words, lens)
+        qlens = np.array([32, 16, 8, 12, 32, 8], dtype=np.uint8)
+        q = _mask_to_len(np.concatenate([base, base[:1], _rand_words(rng, 2, 4, 32)]), qlens)
+        for r, k in [(0, 4096), (1, 4096), (0, 5), (3, 100)]:
+            _check_within(t, keys, words, lens, q, qlens, k, r)
+    finally:
+        t.drop()
+
+
+def test_within_edges(hip_engine):
+    t = hip_engine.open_table(METRIC_HAMMING, 2, 8)
+    try:
+        q = np.array([[5]], dtype=np.uint64)
+        keys, ham, pbits, cnt = t.search_within(q, None, 10, 0)          # empty table
+        assert cnt.tolist() == [0] and t.doc_freq(q).tolist() == [0]
+        t.add(np.array([[1, 1], [1, 2], [2, 1]], dtype=np.uint64), np.array([[5], [5], [7]], dtype=np.uint64))
+        keys, ham, pbits, cnt = t.search_within(q, None, 10, 0)
+        assert cnt.tolist() == [2] and keys[0, :2].tolist() == [[1, 1], [1, 2]] and t.doc_freq(q).tolist() == [1]
+        keys, ham, pbits, cnt = t.search_within(q, None, 10, 1)          # 5 ^ 7 = 2: one bit away
+        assert cnt.tolist() == [3] and ham[0, :3].tolist() == [0, 0, 1]
+        with pytest.raises(ValueError):
+            t.search_within(q, None, 0, 0)
+        with pytest.raises(ValueError):
+            t.search_within(q, None, 10, 257)
+    finally:
+        t.drop()

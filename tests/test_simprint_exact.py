@@ -1,0 +1,164 @@
+"""
+Hard-boundary simprint search (``exact=True``) and document frequency: the reference serves both from an
+LMDB dupsort table (``lmdb_ops.py:139-301``); here a range-limited scan (``max_hamming = 0``) lists the same
+collisions in the same order.  CPU tier: oracle-backed engine; gpu tier: the same assertions through HIP.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_asset, make_iscc_id, sp
+from iscc_search_amd.index import HipIndexManager, HipOptions
+from iscc_search_amd.schema import IsccIndex, IsccQuery
+from iscc_search_amd.simprint import HipSimprintIndex, coverage_quality_score, pack_chunk_pointer
+from oracle_engine import OracleEngine
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "kat_simprint_exact.json")) as f:
+    KAT = json.load(f)
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def engine(request):
+    if request.param == "oracle":
+        yield OracleEngine()
+    else:
+        from iscc_search_amd.engine import HipEngine
+
+        e = HipEngine(0)
+        yield e
+        e.close()
+
+
+def _fill(engine, rows, ndim=64):
+    idx = HipSimprintIndex(engine, ndim=ndim)
+    if rows:
+        keys = [pack_chunk_pointer(bytes.fromhex(body), off, size) for _, body, off, size in rows]
+        vecs = [np.frombuffer(bytes.fromhex(spx), dtype=np.uint8) for spx, _, _, _ in rows]
+        idx.add_raw(keys, vecs)
+    return idx
+
+
+def test_coverage_quality_kats():
+    for c in KAT["coverage_quality"]["cases"]:
+        got = coverage_quality_score([bytes.fromhex(m) for m in c["matched"]], {bytes.fromhex(k): v for k, v in c["doc_freq"].items()}, c["queried"])
+        assert got == c["score"]
+
+
+@pytest.mark.parametrize("case", KAT["doc_freq"]["cases"], ids=lambda c: c["name"])
+def test_doc_freq_kats(engine, case):
+    idx = _fill(engine, case["rows"])
+    assert idx.doc_freq([bytes.fromhex(case["query"])], dup_limit=case.get("dup_limit", 1000)) == [case["freq"]]
+
+
+@pytest.mark.parametrize("case", KAT["search_exact"]["cases"], ids=lambda c: c["name"].split(" ")[0])
+def test_search_exact_kats(engine, case):
+    idx = _fill(engine, case["rows"])
+    res = idx.search_exact([bytes.fromhex(q) for q in case["query"]], limit=case["limit"], threshold=case["threshold"],
+                           detailed=True, dup_limit=case.get("dup_limit", 1000))
+    assert len(res) == len(case["results"])
+    for got, want in zip(res, case["results"]):
+        assert got.iscc_id_body.hex() == want["body"]
+        assert got.score == want["score"]
+        assert (got.queried, got.matches) == (want["queried"], want["matches"])
+        assert [[c.offset, c.size, c.freq] for c in got.chunks] == want["chunks"]
+        assert all(c.score == 1.0 and c.query == c.match for c in got.chunks)
+    if case["results"]:
+        assert idx.search_exact([bytes.fromhex(q) for q in case["query"]], limit=case["limit"], detailed=False)[0].chunks is None
+
+
+def test_search_exact_edges(engine):
+    idx = _fill(engine, [])
+    assert idx.search_exact([b"\xaa" * 8]) == [] and idx.search_exact([]) == []
+    assert idx.doc_freq([b"\xaa" * 8]) == [0] and idx.doc_freq([]) == []
+    idx = _fill(engine, [["aa" * 8, "01" * 8, 0, 100]])
+    # a query simprint of another length collides with nothing, but is still counted as queried
+    res = idx.search_exact([b"\xaa" * 8, b"\xaa" * 16])
+    assert len(res) == 1 and res[0].queried == 2 and res[0].score == 0.5
+    assert idx.doc_freq([b"\xaa" * 16, b"\xaa" * 8]) == [0, 1]
+    # the same query simprint given twice is matched twice (lmdb_ops.py:197), coverage counts it once
+    res = idx.search_exact([b"\xaa" * 8, b"\xaa" * 8], detailed=True)
+    assert res[0].matches == 2 and res[0].queried == 2 and res[0].score == 0.5 and len(res[0].chunks) == 2
+
+
+def test_search_exact_random_against_python_model(engine):
+    """Many collisions, 128-bit simprints: compare with a dict-based model of the LMDB dupsort walk."""
+    rng = np.random.default_rng(11)
+    pool = [rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for _ in range(12)]
+    rows, seen = [], set()
+    while len(rows) < 600:
+        body = int(rng.integers(1, 40)).to_bytes(8, "big")
+        off, size = int(rng.integers(0, 50)) * 10, int(rng.integers(1, 5)) * 100
+        if (body, off, size) in seen:
+            continue
+        seen.add((body, off, size))
+        rows.append([pool[int(rng.integers(0, len(pool)))].hex(), body.hex(), off, size])
+    idx = _fill(engine, rows, ndim=128)
+    query = [pool[0], pool[3], pool[3], pool[7], rng.integers(0, 256, 16, dtype=np.uint8).tobytes()]
+    dup_limit = 25
+    by_sp = {}
+    for spx, body, off, size in rows:
+        by_sp.setdefault(bytes.fromhex(spx), []).append(pack_chunk_pointer(bytes.fromhex(body), off, size))
+    matches, freq = {}, {}
+    for q in query:
+        dups = sorted(by_sp.get(q, []))[:dup_limit]
+        for ptr in dups:
+            matches.setdefault(ptr[:8], []).append((q, int.from_bytes(ptr[8:12], "big"), int.from_bytes(ptr[12:], "big")))
+        if dups:
+            freq[q] = len({ptr[:8] for ptr in dups})
+    want = sorted(((coverage_quality_score([m[0] for m in ms], freq, len(query)), body, ms) for body, ms in matches.items()),
+                  key=lambda r: (-r[0], r[1]))
+    got = idx.search_exact(query, limit=1000, threshold=0.0, detailed=True, dup_limit=dup_limit)
+    assert [(r.score, r.iscc_id_body) for r in got] == [(s, b) for s, b, _ in want]
+    for r, (_, _, ms) in zip(got, want):
+        assert [(c.query, c.offset, c.size, c.freq) for c in r.chunks] == [(q, o, s, freq[q]) for q, o, s in ms]
+    assert idx.doc_freq(query, dup_limit=dup_limit) == [freq.get(q, 0) for q in query]
+
+
+# -- through the protocol backend: usearch/index.py:735-778, :1261-1355 ---------------------------------
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def manager(request):
+    opts = HipOptions(match_threshold_simprints=0.0)   # as the reference's multi-asset case (simprint_exact.py:351)
+    m = HipIndexManager("hip:///", options=opts, engine=OracleEngine()) if request.param == "oracle" else HipIndexManager("hip:///", options=opts)
+    m.create_index(IsccIndex(name="sp"))
+    yield m
+    m.close()
+
+
+def _exact(manager, simprints, limit=10):
+    return manager._index("sp").search_assets(IsccQuery(simprints=simprints), limit=limit, exact=True)
+
+
+def test_exact_mode_through_index(manager):
+    """tests/test_indexes_usearch_simprint_exact.py:88-130, :154-236, :288-372, :438-468."""
+    rng = np.random.default_rng(5)
+    ids = [make_iscc_id(i + 1) for i in range(3)]
+    a, b = b"\xaa" * 8, b"\xbb" * 8
+    manager.add_assets("sp", [
+        make_asset(rng, 1, simprints={"CONTENT_TEXT_V0": [sp(a, 0, 100), sp(b, 100, 200)], "SEMANTIC_TEXT_V0": [sp(b"\xee" * 8, 1000, 300)]},
+                   metadata={"title": "T", "source": "https://example.com/test"}),
+        make_asset(rng, 2, simprints={"CONTENT_TEXT_V0": [sp(a, 0, 150)]}),
+    ])
+    res = _exact(manager, {"CONTENT_TEXT_V0": [sp(a).simprint, sp(b).simprint]})
+    assert [m.iscc_id for m in res.chunk_matches] == [ids[0], ids[1]]
+    assert res.chunk_matches[0].score >= res.chunk_matches[1].score > 0
+    assert str(res.chunk_matches[0].source) == "https://example.com/test" and res.chunk_matches[0].metadata is not None
+    t = res.chunk_matches[0].types["CONTENT_TEXT_V0"]
+    assert (t.matches, t.queried) == (2, 2) and all(c.score == 1.0 for c in t.chunks)
+    # near miss: one flipped bit collides with nothing in exact mode, but matches approximately
+    near = bytes([a[0] ^ 1]) + a[1:]
+    assert _exact(manager, {"CONTENT_TEXT_V0": [sp(near).simprint]}).chunk_matches == []
+    approx = manager.search_assets("sp", IsccQuery(simprints={"CONTENT_TEXT_V0": [sp(near).simprint]}), limit=10)
+    assert len(approx.chunk_matches) >= 1
+    # unknown type, multi-type mean
+    assert _exact(manager, {"NONEXISTENT_V0": [sp(a).simprint]}).chunk_matches == []
+    multi = _exact(manager, {"CONTENT_TEXT_V0": [sp(a).simprint], "SEMANTIC_TEXT_V0": [sp(b"\xee" * 8).simprint]})
+    top = multi.chunk_matches[0]
+    assert top.iscc_id == ids[0] and set(top.types) == {"CONTENT_TEXT_V0", "SEMANTIC_TEXT_V0"}
+    assert top.score == (top.types["CONTENT_TEXT_V0"].score + top.types["SEMANTIC_TEXT_V0"].score) / 2
+    # update replaces the old simprints (remove-then-add)
+    manager.add_assets("sp", [make_asset(rng, 2, simprints={"CONTENT_TEXT_V0": [sp(b"\xcc" * 8, 5, 6)]})])
+    assert [m.iscc_id for m in _exact(manager, {"CONTENT_TEXT_V0": [sp(a).simprint]}).chunk_matches] == [ids[0]]
+    assert [m.iscc_id for m in _exact(manager, {"CONTENT_TEXT_V0": [sp(b"\xcc" * 8).simprint]}).chunk_matches] == [ids[1]]
