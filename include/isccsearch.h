@@ -21,6 +21,13 @@
  *     .search iscc_search/indexes/simprint/usearch_core.py:165   -> isccsearch_search
  *     .get    iscc_search/indexes/simprint/usearch_core.py:221   -> isccsearch_get
  *     `in`    iscc_search/indexes/simprint/usearch_core.py:135   -> isccsearch_contains
+ *   LMDB dupsort simprint table (hard-boundary matching and document frequency; the reference keeps it beside
+ *   the ShardedIndex128, here the same device table answers both)
+ *     search_simprints_exact  iscc_search/indexes/simprint/lmdb_ops.py:169-249 -> isccsearch_search_within (max_hamming 0)
+ *     count_doc_freq          iscc_search/indexes/simprint/lmdb_ops.py:139-166 -> isccsearch_doc_freq (by code),
+ *                                                                                 isccsearch_get_freq (by key)
+ *   LMDB dupsort INSTANCE table
+ *     _search_instance_unit   iscc_search/indexes/usearch/index.py:1957-2022   -> isccsearch_search_within (max_hamming 0)
  *
  * Unlike the reference's HNSW, every search here is EXACT: the k rows with the smallest
  * (distance, key), ascending, where distance is the rational hamming/prefix_bits for NPHD tables
@@ -78,6 +85,7 @@ typedef struct isccsearch_stats {
     uint64_t fallback_queries;/* queries that took the exact full-histogram fallback          */
     uint32_t queries_per_pass;/* T_q: queries held in SGPRs per streaming pass                */
     uint32_t compute_units;   /* CUs of the device                                            */
+    uint64_t freq_builds;     /* document-frequency columns (re)built by isccsearch_get_freq  */
 } isccsearch_stats;
 
 /* Engine lifetime.  One handle drives one GPU (one process per GPU). */
@@ -151,6 +159,15 @@ int isccsearch_search_within(isccsearch_handle* h, uint32_t table, uint32_t nq, 
  * Replaces count_doc_freq (lmdb_ops.py:139-166, called per matched simprint from usearch/index.py:1395-1403). */
 int isccsearch_doc_freq(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                         const uint8_t* q_nbytes, uint32_t dup_limit, uint32_t* out_freq);
+
+/* Document frequency of STORED codes, by key: out_freq[i] = frequency (as isccsearch_doc_freq defines it) of
+ * the code stored under keys[i], 0 when the key is absent.  Served from a per-segment frequency column that is
+ * built on the device by sorting the rows by (code, asset) and is rebuilt lazily after rows were added or
+ * removed -- so the per-match lookups of the approximate simprint path (doc_freq_fn called once per matched
+ * chunk, usearch/index.py:1395-1403 -> usearch_core.py:201-236) cost one gather instead of one scan each.
+ * Hamming (fixed-length) tables only. */
+int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
+                        uint32_t dup_limit, uint32_t* out_freq);
 
 /* Multi-GPU building blocks (row-range shards, one process per GPU).
  * search_device: same search, results left in caller-provided DEVICE memory

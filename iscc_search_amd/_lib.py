@@ -25,7 +25,7 @@ EXPORTS = (
     "isccsearch_stats_get", "isccsearch_table_open", "isccsearch_table_drop", "isccsearch_reserve",
     "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
     "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
-    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_doc_freq",
+    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_doc_freq", "isccsearch_get_freq",
     "isccsearch_search_device", "isccsearch_merge_device",
 )
 
@@ -47,6 +47,7 @@ class Stats(ctypes.Structure):
         ("fallback_queries", ctypes.c_uint64),
         ("queries_per_pass", ctypes.c_uint32),
         ("compute_units", ctypes.c_uint32),
+        ("freq_builds", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -106,6 +107,7 @@ def load_library():
         "isccsearch_search": (i, [vp, u32, u32, u64p, u8p, u32, u64p, u32p, u16p, u32p]),
         "isccsearch_search_within": (i, [vp, u32, u32, u64p, u8p, u32, u32, u64p, u32p, u16p, u32p]),
         "isccsearch_doc_freq": (i, [vp, u32, u32, u64p, u8p, u32, u32p]),
+        "isccsearch_get_freq": (i, [vp, u32, u64, u64p, u32, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
         "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, u64p, u32p, u16p, u32p]),
     }

@@ -27,6 +27,7 @@
 
 #include "../../include/isccsearch.h"
 #include "kernels.hip.h"
+#include "docfreq.h"
 #include "keymap.h"
 
 namespace {
@@ -62,6 +63,11 @@ struct Segment {
     uint64_t* col[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t* keys = nullptr;
     std::vector<uint64_t> hkeys;   // host mirror of the key column, kept only while the table is indexed
+    // document-frequency column (docfreq.hip): built lazily, dropped by every change of the rows
+    uint32_t* freq = nullptr;
+    uint64_t freq_rows = 0;        // rows the column was built for (0 = not built)
+    uint32_t freq_dup = 0;         // dup_limit it was built with
+    void touch() { freq_rows = 0; }
 };
 
 struct Table {
@@ -211,6 +217,9 @@ void seg_free(Segment& s) {
     for (auto& c : s.col) { if (c) (void)hipFree(c); c = nullptr; }
     if (s.keys) (void)hipFree(s.keys);
     s.keys = nullptr;
+    if (s.freq) (void)hipFree(s.freq);
+    s.freq = nullptr;
+    s.freq_rows = 0;
     s.n = s.cap = 0;
     s.hkeys.clear();
     s.hkeys.shrink_to_fit();
@@ -902,6 +911,7 @@ int isccsearch_add(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
             }
         }
         s.n += m;
+        s.touch();
         t.total += m;
     }
     return 0;
@@ -977,6 +987,7 @@ int isccsearch_add_columns(isccsearch_handle* h, uint32_t table, int nbytes, uin
         }
     }
     s.n += n;
+    s.touch();
     t.total += n;
     return 0;
 }
@@ -1005,6 +1016,7 @@ int isccsearch_add_synthetic(isccsearch_handle* h, uint32_t table, int nbytes, u
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(h->stream));
     s.n += n;
+    s.touch();
     t.total += n;
     return 0;
 }
@@ -1040,6 +1052,7 @@ int isccsearch_remove(isccsearch_handle* h, uint32_t table, uint64_t n, const ui
         }
         s.hkeys.resize((size_t)last * KW);
         s.n = last;
+        s.touch();
         t.total--;
         ++removed;
     }
@@ -1120,6 +1133,62 @@ int isccsearch_get(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
         HIPOK(hipStreamSynchronize(h->stream));
         for (uint64_t i = 0; i < m; ++i)
             for (uint32_t w = 0; w < s.W; ++w) out_words[dest[b][i] * MW + w] = tmp[i * s.W + w];
+    }
+    return 0;
+}
+
+// freq[i] = document frequency of the code stored under keys[i] (0 when the key is absent), read from the
+// segment's document-frequency column; the column is (re)built here when rows changed since it was made.
+int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
+                        uint32_t dup_limit, uint32_t* out_freq) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (dup_limit < 1) return fail(-EINVAL, "dup_limit must be >= 1");
+    if (n == 0) return 0;
+    if (!keys || !out_freq) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    if (t.metric != ISCCSEARCH_METRIC_HAMMING) return fail(-EINVAL, "get_freq is defined for fixed-length (Hamming) tables");
+    HIPOK(hipSetDevice(h->device));
+    if ((rc = ensure_index(h, t))) return rc;
+    const int KW = t.key_words;
+    memset(out_freq, 0, (size_t)n * sizeof(uint32_t));
+    std::vector<uint64_t> rows[ISCCSEARCH_MAX_BYTES + 1], dest[ISCCSEARCH_MAX_BYTES + 1];
+    for (uint64_t i = 0; i < n; ++i) {
+        Key k = KW == 2 ? Key{keys[2 * i], keys[2 * i + 1]} : Key{0, keys[i]};
+        Loc loc;
+        if (!t.index.find(k, loc)) continue;
+        rows[loc.seg].push_back(loc.row);
+        dest[loc.seg].push_back(i);
+    }
+    std::vector<uint32_t> tmp;
+    for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
+        if (rows[b].empty()) continue;
+        Segment& s = t.seg[b];
+        if (s.freq_rows != s.n || s.freq_dup != dup_limit) {
+            if (s.freq) { (void)hipFree(s.freq); s.freq = nullptr; }
+            s.freq_rows = 0;
+            hipError_t e = hipMalloc((void**)&s.freq, s.n * sizeof(uint32_t));
+            if (e != hipSuccess) { s.freq = nullptr; return fail(-ENOMEM, "hipMalloc(frequency column, %llu bytes) failed: %s", (unsigned long long)s.n * 4, hipGetErrorString(e)); }
+            std::string err;
+            if ((rc = iskdf::build_freq_column(s.col, (int)s.W, s.keys, KW, s.n, dup_limit, s.freq, h->stream, &err))) return fail(rc, "%s", err.c_str());
+            s.freq_rows = s.n;
+            s.freq_dup = dup_limit;
+            h->stats.freq_builds += 1;
+        }
+        const uint64_t m = rows[b].size();
+        if ((rc = h->d_misc.ensure(m))) return rc;
+        if ((rc = h->d_freq.ensure(m))) return rc;
+        HIPOK(hipMemcpyAsync(h->d_misc.p, rows[b].data(), m * 8, hipMemcpyHostToDevice, h->stream));
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((m + isk::BLOCK - 1) / isk::BLOCK, 1024);
+        hipLaunchKernelGGL(isk::gather_u32_kernel, dim3(grid), dim3(isk::BLOCK), 0, h->stream, s.freq, h->d_misc.p, h->d_freq.p, m);
+        HIPOK(hipGetLastError());
+        tmp.resize(m);
+        HIPOK(hipMemcpyAsync(tmp.data(), h->d_freq.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        for (uint64_t i = 0; i < m; ++i) out_freq[dest[b][i]] = tmp[i];
     }
     return 0;
 }

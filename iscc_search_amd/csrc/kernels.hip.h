@@ -863,4 +863,9 @@ __global__ __launch_bounds__(BLOCK) void gather_rows_kernel(const GatherParams p
         for (uint32_t w = 0; w < p.W; ++w) p.out[i * p.W + w] = p.col[w][p.rows[i]];
 }
 
+// out[i] = src[rows[i]]  (document-frequency column lookups)
+__global__ __launch_bounds__(BLOCK) void gather_u32_kernel(const uint32_t* src, const uint64_t* rows, uint32_t* out, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) out[i] = src[rows[i]];
+}
+
 }  // namespace isk

@@ -302,6 +302,20 @@ class HipTable:
             )
         return out
 
+    def get_freq(self, keys, dup_limit=1000):
+        # type: (np.ndarray, int) -> np.ndarray
+        """
+        Document frequency of the code stored under each key (0 for absent keys), from the segment's
+        frequency column (built lazily on the device after the rows changed) -> uint32 [n].
+        """
+        keys = self._keys(keys)
+        n = keys.shape[0]
+        out = np.zeros(n, dtype=np.uint32)
+        if n:
+            _lib.check(self.engine._lib.isccsearch_get_freq(
+                self.engine.handle, self.id, n, _lib.ptr(keys, ctypes.c_uint64), int(dup_limit), _lib.ptr(out, ctypes.c_uint32)))
+        return out
+
     def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr):
         # type: (np.ndarray, np.ndarray | None, int, int, int) -> None
         """Same search, results left in caller-owned device memory (multi-GPU exchange)."""

@@ -90,7 +90,6 @@ class HipIndex:
         self._unit_tables = {}  # type: Dict[str, HipNphdIndex]
         self._sp_tables = {}  # type: Dict[str, HipSimprintIndex]
         self._sp_assets = {}  # type: Dict[str, Dict[bytes, list]]   sp_type -> body -> [(sp_bytes, chunk_ptr)]
-        self._sp_freq = {}  # type: Dict[str, Dict[bytes, Dict[bytes, int]]]  sp_type -> sp_bytes -> {body: n}
         self.dirty = False
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -108,16 +107,11 @@ class HipIndex:
         if t is None:
             t = self._sp_tables[sp_type] = HipSimprintIndex(self._engine, ndim=ndim, oversampling_factor=self._opts.oversampling_factor)
             self._sp_assets[sp_type] = {}
-            self._sp_freq[sp_type] = {}
         return t
 
     @staticmethod
     def _fingerprint(sp_list):
         return tuple(sorted((codec.decode_base64(sp.simprint), sp.offset, sp.size) for sp in sp_list))
-
-    def _doc_freq(self, sp_type, sp_bytes):
-        # distinct assets carrying exactly this simprint (``lmdb_ops.count_doc_freq``, :139-166)
-        return len(self._sp_freq.get(sp_type, {}).get(sp_bytes, ()))
 
     # -- add ---------------------------------------------------------------------------------------
     def add_assets(self, assets):
@@ -183,19 +177,9 @@ class HipIndex:
                     old = self._sp_assets[sp_type].pop(body, None)
                     if old is not None:
                         sp_deleted.setdefault(sp_type, []).extend(ptr for _, ptr in old)
-                        for sp_bytes, _ in old:
-                            owners = self._sp_freq[sp_type].get(sp_bytes)
-                            if owners is not None:
-                                owners[body] = owners.get(body, 1) - 1
-                                if owners[body] <= 0:
-                                    del owners[body]
-                                if not owners:
-                                    del self._sp_freq[sp_type][sp_bytes]
                     self._sp_assets[sp_type][body] = pairs
                     keys_b, vecs_b = sp_batches.setdefault(sp_type, ([], []))
                     for sp_bytes, ptr in pairs:
-                        owners = self._sp_freq[sp_type].setdefault(sp_bytes, {})
-                        owners[body] = owners.get(body, 0) + 1
                         keys_b.append(ptr)
                         vecs_b.append(np.frombuffer(sp_bytes, dtype=np.uint8))
 
@@ -331,7 +315,7 @@ class HipIndex:
             else:
                 raw = table.search_raw(
                     simprints=q_bytes, limit=limit * 2, threshold=self._opts.match_threshold_simprints, detailed=True,
-                    doc_freq_fn=lambda sp, _t=sp_type: self._doc_freq(_t, sp), total_assets=total_assets,
+                    total_assets=total_assets, device_doc_freq=True,   # lmdb_ops.count_doc_freq, on the device
                 )
             for r in raw:
                 per_asset.setdefault(r.iscc_id_body, {})[sp_type] = r
@@ -415,12 +399,10 @@ class HipIndex:
         for sp_type, ndim in meta["simprint_types"].items():
             table = idx._sp_table(sp_type, ndim)
             table.load(os.path.join(path, "simprints", sp_type))
-            # host-side maps (per-asset chunk lists, document frequencies) are derived from the stored rows
+            # the host-side per-asset chunk lists are derived from the stored rows
             for ckey, sp_bytes in table.rows():
                 body = unpack_chunk_pointer(ckey)[0]
                 idx._sp_assets[sp_type].setdefault(body, []).append((sp_bytes, ckey))
-                owners = idx._sp_freq[sp_type].setdefault(sp_bytes, {})
-                owners[body] = owners.get(body, 0) + 1
         return idx
 
     def close(self):

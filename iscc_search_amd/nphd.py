@@ -373,6 +373,13 @@ class HipIndex128:
             out.append(Matches(words_to_key128(keys[q, :c]), ham[q, :c].astype(np.float32), ham[q, :c].copy(), pbits[q, :c].copy()))
         return out[0] if single else BatchMatches(out)
 
+    def get_freq(self, keys, dup_limit=1000):
+        # type: (list[bytes], int) -> np.ndarray
+        """Document frequency of the vector stored under each key (0 for absent keys), from the frequency column."""
+        if len(keys) == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return self._table.get_freq(key128_to_words(keys), dup_limit)
+
     def doc_freq(self, vectors, dup_limit=1000):
         # type: (np.ndarray, int) -> np.ndarray
         """Distinct assets (key[:8]) among the first ``dup_limit`` rows equal to each vector (``lmdb_ops.py:139-166``)."""

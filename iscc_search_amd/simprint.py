@@ -128,9 +128,17 @@ class HipSimprintIndex:
     def size(self):
         return len(self._index)
 
-    def search_raw(self, simprints, limit=10, threshold=0.0, detailed=False, doc_freq_fn=None, total_assets=0):
-        # type: (list[bytes], int, float, bool, Callable[[bytes], int] | None, int) -> list[SimprintMatchRaw]
-        """Oversampled batched search + IDF-weighted asset scoring (``usearch_core.py:137-269``)."""
+    def search_raw(self, simprints, limit=10, threshold=0.0, detailed=False, doc_freq_fn=None, total_assets=0, device_doc_freq=False):
+        # type: (list[bytes], int, float, bool, Callable[[bytes], int] | None, int, bool) -> list[SimprintMatchRaw]
+        """
+        Oversampled batched search + IDF-weighted asset scoring (``usearch_core.py:137-269``).
+
+        ``doc_freq_fn`` is the reference's per-simprint callback (``None``: every frequency is 1).  With
+        ``device_doc_freq`` the frequencies come from the device instead -- the stored simprints' from the
+        table's frequency column (one gather for all matched chunks), the unmatched query simprints' from
+        one collision scan -- which is what the reference's callback computes with an LMDB cursor walk per
+        simprint (``usearch/index.py:1395-1403``, ``lmdb_ops.py:139-166``).
+        """
         if not simprints or len(self._index) == 0:
             return []
         queries = np.stack([np.frombuffer(s, dtype=np.uint8) for s in simprints])
@@ -153,17 +161,28 @@ class HipSimprintIndex:
         if not asset_best:
             return []
 
-        freq_cache = {}
-
-        def get_freq(sp):
-            if sp not in freq_cache:
-                freq_cache[sp] = doc_freq_fn(sp) if doc_freq_fn is not None else 1
-            return freq_cache[sp]
-
         # stored vectors of every winning chunk in ONE device round trip (the reference does one
         # `get` per chunk, usearch_core.py:221)
         all_keys = [v[3] for best in asset_best.values() for v in best.values()]
         fetched = dict(zip(all_keys, self._index.get_many(all_keys)))
+
+        freq_cache = {}
+        if device_doc_freq:
+            for ckey, f in zip(all_keys, self._index.get_freq(all_keys)):
+                vec = fetched.get(ckey)
+                if vec is not None:
+                    freq_cache[vec.tobytes()] = int(f)
+            missing = [sp for sp in dict.fromkeys(simprints) if sp not in freq_cache]
+            if missing and any(len(best) < len(simprints) for best in asset_best.values()):
+                freq_cache.update(zip(missing, self.doc_freq(missing)))
+
+        def get_freq(sp):
+            if sp not in freq_cache:
+                if device_doc_freq:
+                    freq_cache[sp] = self.doc_freq([sp])[0]
+                else:
+                    freq_cache[sp] = doc_freq_fn(sp) if doc_freq_fn is not None else 1
+            return freq_cache[sp]
 
         results = []
         for asset_id, best in asset_best.items():

@@ -128,6 +128,13 @@ class OracleTable:
             out[q] = len(np.unique(assets))
         return out
 
+    def get_freq(self, keys, dup_limit=1000):
+        words, nb = self.get(keys)
+        out = np.zeros(len(nb), dtype=np.uint32)
+        for i in np.nonzero(nb)[0]:
+            out[i] = self.doc_freq(words[i : i + 1], nb[i : i + 1], dup_limit)[0]
+        return out
+
     def search_records(self, q_words, q_nbytes, k):
         """Structured records [nq, k] + counts, as the device exchange format."""
         keys, ham, pbits, cnt = self.search(q_words, q_nbytes, k)

@@ -119,3 +119,76 @@ def test_within_edges(hip_engine):
             t.search_within(q, None, 10, 257)
     finally:
         t.drop()
+
+
+def _freq_model(keys, words, dup_limit):
+    """Per row: distinct assets among the first dup_limit rows (ascending key) holding the same code."""
+    groups = {}
+    for i in range(len(keys)):
+        groups.setdefault(words[i].tobytes(), []).append(i)
+    out = np.zeros(len(keys), dtype=np.uint32)
+    for rows in groups.values():
+        if keys.ndim == 2:
+            rows_sorted = sorted(rows, key=lambda r: (int(keys[r, 0]), int(keys[r, 1])))[:dup_limit]
+            f = len({int(keys[r, 0]) for r in rows_sorted})
+        else:
+            f = min(len(rows), dup_limit)
+        out[rows] = f
+    return out
+
+
+@pytest.mark.parametrize("nbytes,key_words", [(8, 2), (16, 2), (32, 2), (13, 2), (8, 1)])
+def test_frequency_column_vs_model(hip_engine, nbytes, key_words):
+    """isccsearch_get_freq (sort-based column) == the dict model == isccsearch_doc_freq (collision scan)."""
+    rng = np.random.default_rng(500 + nbytes + key_words)
+    n = 30000
+    t = hip_engine.open_table(METRIC_HAMMING, key_words, nbytes)
+    try:
+        mw = t.max_words
+        pool = _rand_words(rng, 400, mw, nbytes)
+        pool[1] = pool[0]
+        pool[1, mw - 1] ^= np.uint64(1) << np.uint64(63)     # differs from pool[0] in the LAST word only
+        pick = np.minimum(rng.geometric(0.02, size=n) - 1, 399)   # skewed: a few codes are very common
+        words = pool[pick]
+        words[n // 2:] = _rand_words(rng, n - n // 2, mw, nbytes)  # and half the rows are unique
+        if key_words == 2:
+            keys = np.stack([rng.integers(1, 60, size=n).astype(np.uint64), rng.permutation(n).astype(np.uint64)], axis=1)
+        else:
+            keys = rng.permutation(np.arange(n, dtype=np.uint64) * np.uint64(31) + np.uint64(9))
+        t.add(keys, words)
+        builds = hip_engine.stats()["freq_builds"]
+        for dup_limit in (1000, 7):
+            want = _freq_model(keys, words, dup_limit)
+            got = t.get_freq(keys, dup_limit)
+            np.testing.assert_array_equal(got, want)
+            sample = rng.integers(0, n, size=40)
+            np.testing.assert_array_equal(t.doc_freq(words[sample], None, dup_limit), want[sample])
+        assert hip_engine.stats()["freq_builds"] == builds + 2          # one build per dup_limit, reused by lookups
+        t.get_freq(keys[:10], 7)
+        assert hip_engine.stats()["freq_builds"] == builds + 2
+        # absent keys -> 0; rows changing -> the column is rebuilt
+        absent = keys[:3].copy()
+        if key_words == 2:
+            absent[:, 1] += np.uint64(10**15)
+        else:
+            absent += np.uint64(10**15)
+        assert t.get_freq(absent).tolist() == [0, 0, 0]
+        t.remove(keys[:5000])
+        keys2, words2 = keys[5000:], words[5000:]
+        np.testing.assert_array_equal(t.get_freq(keys2, 1000), _freq_model(keys2, words2, 1000))
+        extra_k = keys[:100].copy()
+        t.add(extra_k, words2[:100])
+        keys3, words3 = np.concatenate([keys2, extra_k]), np.concatenate([words2, words2[:100]])
+        np.testing.assert_array_equal(t.get_freq(keys3, 1000), _freq_model(keys3, words3, 1000))
+    finally:
+        t.drop()
+
+
+def test_frequency_column_is_for_fixed_length_tables(hip_engine):
+    t = hip_engine.open_table(METRIC_NPHD, 1, 32)
+    try:
+        t.add(np.array([1], dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64), np.array([8], dtype=np.uint8))
+        with pytest.raises(ValueError):
+            t.get_freq(np.array([1], dtype=np.uint64))
+    finally:
+        t.drop()

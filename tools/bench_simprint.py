@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end timing of HipSimprintIndex.search_raw (config 5 shape): GPU search + host IDF scoring."""
+"""End-to-end timing of HipSimprintIndex (config 5 shape): approximate search_raw (GPU search + host IDF scoring,
+document frequencies from the device), hard-boundary search_exact, and the frequency-column build."""
 import os
 import sys
 import time
@@ -32,8 +33,16 @@ for nq in (16, 64, 256):
     q[:, 0] ^= 3
     simprints = [bytes(r) for r in q]
     for limit in (10,):
+        for mode, kw in (("callback freq=1", dict(doc_freq_fn=lambda s: 1)), ("device doc freq", dict(device_doc_freq=True)), ("device doc freq", dict(device_doc_freq=True))):
+            b0 = eng.stats()["freq_builds"]
+            t0 = time.perf_counter()
+            res = idx.search_raw(simprints, limit=limit * 2, threshold=0.75, detailed=True, total_assets=n_assets, **kw)
+            dt = time.perf_counter() - t0
+            built = eng.stats()["freq_builds"] - b0
+            print(f"search_raw nq={nq} limit={limit*2} (count={limit*2*20}) {mode}{' [column built]' if built else ''}: "
+                  f"{dt*1e3:8.2f} ms, {len(res)} assets, top score {res[0].score:.4f}")
+        exact_q = [bytes(r) for r in first[:nq]]
         t0 = time.perf_counter()
-        res = idx.search_raw(simprints, limit=limit * 2, threshold=0.75, detailed=True, doc_freq_fn=lambda s: 1, total_assets=n_assets)
-        dt = time.perf_counter() - t0
-        print(f"search_raw nq={nq} limit={limit*2} (count={limit*2*20}): {dt*1e3:8.2f} ms, {len(res)} assets, top score {res[0].score:.4f}")
+        res = idx.search_exact(exact_q, limit=limit * 2, threshold=0.0, detailed=True)
+        print(f"search_exact nq={nq}: {(time.perf_counter() - t0)*1e3:8.2f} ms, {len(res)} assets")
 eng.close()
