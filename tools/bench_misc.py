@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements (not the driver's bench): latency, small tables, large k, mixed lengths.
 
-  python tools/bench_misc.py [latency] [small] [simprint] [mixed]
+  python tools/bench_misc.py [latency] [small] [simprint] [mixed] [threads] [within]
 """
 import os
 import sys
@@ -25,7 +25,7 @@ def timeit(fn, reps=10, warm=2):
 
 
 def main():
-    what = set(sys.argv[1:]) or {"latency", "small", "simprint", "mixed", "threads"}
+    what = set(sys.argv[1:]) or {"latency", "small", "simprint", "mixed", "threads", "within"}
     eng = HipEngine(0)
     rng = np.random.default_rng(0)
     if "latency" in what:
@@ -58,6 +58,43 @@ def main():
                 q = rng.integers(0, 2**64, size=(nq, t.max_words), dtype=np.uint64)
                 dt = timeit(lambda: t.search(q, None, k), reps=3, warm=1)
                 print(f"simprint: {n} x {nbytes*8}-bit (128-bit keys), nq={nq}, k={k}: {dt*1e3:9.3f} ms/call ({nq/dt:8.0f} qps)")
+            t.drop()
+    if "within" in what:
+        # range-limited search (collision lookup) and the document-frequency column
+        t = eng.open_table(_lib.METRIC_HAMMING, 1, 8)
+        t.add_synthetic(8, 100_000_000, 1)
+        _, cols = t.export_rows(8, 12345, 1024)
+        stored = cols.T.copy()
+        for nq in (1, 16, 1024):
+            q = stored[:nq]
+            for r, k in ((0, 1000), (4, 1000)):
+                dt = timeit(lambda: t.search_within(q, None, k, r), reps=5, warm=1)
+                print(f"within: 100M x 64-bit, nq={nq:4d}, max_hamming={r}, k={k}: {dt*1e3:8.3f} ms/call ({nq/dt:9.0f} qps)")
+            dt = timeit(lambda: t.search(q, None, 10), reps=5, warm=1)
+            print(f"        same queries, plain top-10 search:              {dt*1e3:8.3f} ms/call")
+        t.drop()
+        for nbytes, n in ((16, 10_000_000), (32, 10_000_000), (8, 50_000_000)):
+            t = eng.open_table(_lib.METRIC_HAMMING, 2, nbytes)
+            t.add_synthetic(nbytes, n, 7)
+            probe = np.array([[0, 5]], dtype=np.uint64)
+            t0 = time.perf_counter()
+            t.get_freq(probe)                       # host key index + first column build
+            first = time.perf_counter() - t0
+            extra = np.array([[1, 1]], dtype=np.uint64)
+            w = np.zeros((1, t.max_words), dtype=np.uint64)
+            times = []
+            for i in range(3):
+                t.remove(extra) if i else None
+                t.add(extra, w)                     # rows changed -> the column is rebuilt by the next lookup
+                t0 = time.perf_counter()
+                t.get_freq(probe)
+                times.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                t.get_freq(probe)
+            look = (time.perf_counter() - t0) / 20
+            print(f"freq column: {n} x {nbytes*8}-bit rows (128-bit keys): first call {first*1e3:8.1f} ms (incl. host key index), "
+                  f"rebuild {min(times)*1e3:7.2f} ms, lookup {look*1e3:6.3f} ms")
             t.drop()
     if "threads" in what:
         # the reference's call shape under load: many threads, ONE query per call (k = 100 = its default limit)
