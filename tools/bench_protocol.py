@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import make_asset  # noqa: E402
-from iscc_search_amd.index import HipIndexManager  # noqa: E402
+from iscc_search_amd.index import HipIndexManager, normalize_query  # noqa: E402
 from iscc_search_amd.schema import IsccIndex, IsccQuery  # noqa: E402
 
 rng = np.random.default_rng(0)
@@ -49,3 +49,16 @@ for th in threads:
 dt = time.perf_counter() - t0
 print(f"search_assets, 16 threads: {len(queries) / dt:.0f} searches/s")
 m.close()
+
+# py-memory-style: what the reference's memory:// backend does per search -- normalise the query,
+# then compare iscc_code strings against EVERY stored asset, score 1.0 (iscc_search/indexes/memory/index.py:204-232).
+# One core, GIL-bound by construction; no distance is computed, so this is a plumbing baseline only.
+store = {a.iscc_id: a for a in assets}
+t0 = time.perf_counter()
+for q in queries:
+    nq = normalize_query(q)
+    types = {u: 1.0 for u in nq.units or []}
+    hits = [(a.iscc_id, 1.0, types, a.metadata) for a in store.values() if nq.iscc_code and a.iscc_code and a.iscc_code == nq.iscc_code][:10]
+    assert len(hits) == 1
+dt = time.perf_counter() - t0
+print(f"py-memory-style loop over {n_assets} assets, 1 core: {len(queries) / dt:.0f} searches/s ({dt / len(queries) * 1e3:.2f} ms each)")
