@@ -2,7 +2,8 @@
 Randomised differential test: a sequence of add / remove / search operations on HIP tables, mirrored on
 the oracle-backed model table (tests/oracle_engine.py), compared bit for bit after every search.
 Covers both metrics, both key widths, every code length 1..32 bytes, k from 1 to 4096, batches larger
-than one pipeline run (1 024 queries), all queries-per-pass settings, heavy ties and tiny tables.
+than one pipeline run (1 024 queries), all queries-per-pass settings, heavy ties and tiny tables; plus the
+range-limited search and both document-frequency entry points.
 """
 
 import os
@@ -56,7 +57,7 @@ def test_random_operation_sequences(hip_engine, seed):
     live = []
     try:
         for step in range(14):
-            op = rng.choice(["add", "add", "remove", "search", "search"])
+            op = rng.choice(["add", "add", "remove", "search", "search", "within"])
             if op == "add" or not live:
                 n = int(rng.choice([1, 7, 300, 5000, 40000]))
                 lens = rng.choice(lengths, size=n).astype(np.uint8)
@@ -83,6 +84,23 @@ def test_random_operation_sequences(hip_engine, seed):
                     pick = rng.choice(len(mk), size=min(len(mk), int(rng.choice([1, 50, 3000]))), replace=False)
                     victims = mk[pick]
                     assert t.remove(victims) == model.remove(victims)
+            elif op == "within":
+                # range-limited search, document frequency by code and by key (fixed-length tables)
+                nq = int(rng.choice([1, 5, 24]))
+                k = int(rng.choice([1, 10, 1000, 4096]))
+                r = int(rng.choice([0, 0, 1, 3, 10, 8 * max_bytes]))
+                qlens = rng.choice(lengths, size=nq).astype(np.uint8) if metric == 1 else None
+                q = bases[rng.integers(0, len(bases), size=nq)].copy()
+                q[:, 0] ^= rng.integers(0, 4, size=nq).astype(np.uint64) << np.uint64(61)
+                q = _mask(q, qlens if metric == 1 else max_bytes)
+                tag = f"seed={seed} step={step} tq={tq} nq={nq} k={k} r={r}"
+                _compare(t.search_within(q, qlens, k, r), model.search_within(q, qlens, k, r), "within " + tag)
+                dup = int(rng.choice([1000, 3]))
+                np.testing.assert_array_equal(t.doc_freq(q, qlens, dup), model.doc_freq(q, qlens, dup), err_msg="doc_freq " + tag)
+                if metric == 0:
+                    mk, _, _ = model._arrays()
+                    some = mk[rng.choice(len(mk), size=min(len(mk), 12), replace=False)]
+                    np.testing.assert_array_equal(t.get_freq(some, dup), model.get_freq(some, dup), err_msg="get_freq " + tag)
             else:
                 nq = int(rng.choice([1, 5, 37, 1100]))
                 k = int(rng.choice([1, 10, 100, 1000, 4096]))
