@@ -180,6 +180,10 @@ int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const 
  *   per-rank blocks {records | counts} can be merged in place. */
 int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                              const uint8_t* q_nbytes, uint32_t k, void* d_records, uint32_t* d_counts);
+/* search_within_device: the range-limited search (isccsearch_search_within) with device-resident results. */
+int isccsearch_search_within_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                                    const uint8_t* q_nbytes, uint32_t k, uint32_t max_hamming,
+                                    void* d_records, uint32_t* d_counts);
 int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
                             const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
                             uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);

@@ -26,7 +26,7 @@ EXPORTS = (
     "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
     "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
     "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_doc_freq", "isccsearch_get_freq",
-    "isccsearch_search_device", "isccsearch_merge_device",
+    "isccsearch_search_device", "isccsearch_search_within_device", "isccsearch_merge_device",
 )
 
 RECORD_DTYPE = np.dtype(
@@ -109,6 +109,7 @@ def load_library():
         "isccsearch_doc_freq": (i, [vp, u32, u32, u64p, u8p, u32, u32p]),
         "isccsearch_get_freq": (i, [vp, u32, u64, u64p, u32, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
+        "isccsearch_search_within_device": (i, [vp, u32, u32, u64p, u8p, u32, u32, vp, vp]),
         "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, u64p, u32p, u16p, u32p]),
     }
     for name, (res, args) in sig.items():

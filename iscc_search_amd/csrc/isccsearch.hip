@@ -1424,11 +1424,12 @@ int isccsearch_doc_freq(isccsearch_handle* h, uint32_t table, uint32_t nq, const
     return search_locked(h, table, nq, q_words, q_nbytes, dup_limit, nullptr, nullptr, nullptr, nullptr, 0, out_freq);
 }
 
-int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
-                             const uint8_t* q_nbytes, uint32_t k, void* d_records, uint32_t* d_counts) {
+static int search_device_impl(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                              const uint8_t* q_nbytes, uint32_t k, int radius, void* d_records, uint32_t* d_counts) {
     if (!h) return fail(-EINVAL, "handle is NULL");
     if (k < 1) return fail(-EINVAL, "`count` must be >= 1");
     if (k > ISCCSEARCH_MAX_K) return fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", k, ISCCSEARCH_MAX_K);
+    if (radius > 256) return fail(-EINVAL, "max_hamming %d exceeds 256", radius);
     if (nq == 0) return 0;
     if (!q_words || !d_records || !d_counts) return fail(-EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1450,10 +1451,23 @@ int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, 
     for (uint32_t pos = 0; pos < nq; pos += QB_MAX) {
         const uint32_t m = std::min<uint32_t>(QB_MAX, nq - pos);
         Batch batch(h, t, m, len, k, out + (size_t)pos * k, d_counts + pos);
+        batch.radius = radius;
         if ((rc = batch.run_to_device(q_words + (size_t)pos * t.max_words))) return rc;
     }
     HIPOK(hipStreamSynchronize(h->stream));
     return 0;
+}
+
+int isccsearch_search_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                             const uint8_t* q_nbytes, uint32_t k, void* d_records, uint32_t* d_counts) {
+    return search_device_impl(h, table, nq, q_words, q_nbytes, k, -1, d_records, d_counts);
+}
+
+int isccsearch_search_within_device(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                                    const uint8_t* q_nbytes, uint32_t k, uint32_t max_hamming,
+                                    void* d_records, uint32_t* d_counts) {
+    if (max_hamming > 256) return fail(-EINVAL, "max_hamming %u exceeds 256", max_hamming);
+    return search_device_impl(h, table, nq, q_words, q_nbytes, k, (int)max_hamming, d_records, d_counts);
 }
 
 int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,

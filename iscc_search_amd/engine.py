@@ -316,18 +316,18 @@ class HipTable:
                 self.engine.handle, self.id, n, _lib.ptr(keys, ctypes.c_uint64), int(dup_limit), _lib.ptr(out, ctypes.c_uint32)))
         return out
 
-    def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr):
-        # type: (np.ndarray, np.ndarray | None, int, int, int) -> None
-        """Same search, results left in caller-owned device memory (multi-GPU exchange)."""
+    def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr, max_hamming=None):
+        # type: (np.ndarray, np.ndarray | None, int, int, int, int | None) -> None
+        """Same search (range-limited when ``max_hamming`` is given), results left in caller-owned device memory."""
         q_words = self._words(q_words)
         nq = q_words.shape[0]
         q_nbytes = self._nbytes(q_nbytes, nq)
-        _lib.check(
-            self.engine._lib.isccsearch_search_device(
-                self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k,
-                ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr),
-            )
-        )
+        lib, args = self.engine._lib, (self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k)
+        out = (ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr))
+        if max_hamming is None:
+            _lib.check(lib.isccsearch_search_device(*args, *out))
+        else:
+            _lib.check(lib.isccsearch_search_within_device(*args, int(max_hamming), *out))
 
     # -- snapshot (raw little-endian column files; SURVEY.md section 8f item 2) --------------------------
     def segments(self):

@@ -52,15 +52,15 @@ class HipShardOps:
         self.device = torch.device(device)
         self.key_words = table.key_words
 
-    def local_search(self, q_words, q_nbytes, k):
-        """One device block {records | counts} holding this shard's exact top-k."""
+    def local_search(self, q_words, q_nbytes, k, max_hamming=None):
+        """One device block {records | counts} holding this shard's exact top-k (within ``max_hamming`` if given)."""
         torch = self.torch
         nq = q_words.shape[0]
         rec_bytes, blk = block_bytes(nq, k)
         buf = torch.empty(blk, dtype=torch.uint8, device=self.device)
         # the library drains its own stream before returning, so the block can go straight into
         # the collective on torch's stream
-        self.table.search_device(q_words, q_nbytes, k, buf.data_ptr(), buf.data_ptr() + rec_bytes)
+        self.table.search_device(q_words, q_nbytes, k, buf.data_ptr(), buf.data_ptr() + rec_bytes, max_hamming=max_hamming)
         return buf
 
     def merge(self, gathered, n_lists, nq, k):
@@ -89,8 +89,33 @@ class ShardedTable:
 
     def search(self, q_words, q_nbytes, k):
         # type: (np.ndarray, np.ndarray | None, int) -> tuple
+        return self._search(q_words, q_nbytes, k, None)
+
+    def search_within(self, q_words, q_nbytes, k, max_hamming):
+        # type: (np.ndarray, np.ndarray | None, int, int) -> tuple
+        """
+        Range-limited search over all shards: each rank lists its rows within ``max_hamming`` (nearest first, at most
+        k), the same all-gather + merge keeps the k nearest overall -- the lists are ordered by (distance, key), so
+        the merged list equals the unsharded one.
+        """
+        return self._search(q_words, q_nbytes, k, int(max_hamming))
+
+    def doc_freq(self, q_words, q_nbytes=None, dup_limit=1000):
+        # type: (np.ndarray, np.ndarray | None, int) -> np.ndarray
+        """
+        Distinct assets among the first ``dup_limit`` collisions of each code across ALL shards.  An asset's chunks
+        may sit on different ranks, so the per-shard counts cannot be added: the merged collision list is reduced.
+        """
+        keys, _, _, cnt = self.search_within(q_words, q_nbytes, dup_limit, 0)
+        out = np.zeros(len(cnt), dtype=np.uint32)
+        for q, c in enumerate(cnt):
+            assets = keys[q, :c, 0] if keys.ndim == 3 else keys[q, :c]
+            out[q] = len(np.unique(assets))
+        return out
+
+    def _search(self, q_words, q_nbytes, k, max_hamming):
         nq = q_words.shape[0]
-        block = self.ops.local_search(q_words, q_nbytes, k)
+        block = self.ops.local_search(q_words, q_nbytes, k) if max_hamming is None else self.ops.local_search(q_words, q_nbytes, k, max_hamming)
         if self.world_size == 1 and not (self.always_gather and self.dist.is_initialized()):
             return self.ops.merge(block, 1, nq, k)
         import torch

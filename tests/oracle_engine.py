@@ -135,9 +135,12 @@ class OracleTable:
             out[i] = self.doc_freq(words[i : i + 1], nb[i : i + 1], dup_limit)[0]
         return out
 
-    def search_records(self, q_words, q_nbytes, k):
+    def search_records(self, q_words, q_nbytes, k, max_hamming=None):
         """Structured records [nq, k] + counts, as the device exchange format."""
-        keys, ham, pbits, cnt = self.search(q_words, q_nbytes, k)
+        if max_hamming is None:
+            keys, ham, pbits, cnt = self.search(q_words, q_nbytes, k)
+        else:
+            keys, ham, pbits, cnt = self.search_within(q_words, q_nbytes, k, max_hamming)
         ranks = rank_table()
         nq = q_words.shape[0]
         rec = np.zeros((nq, k), dtype=RECORD_DTYPE)

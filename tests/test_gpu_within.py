@@ -192,3 +192,41 @@ def test_frequency_column_is_for_fixed_length_tables(hip_engine):
             t.get_freq(np.array([1], dtype=np.uint64))
     finally:
         t.drop()
+
+
+def test_two_shards_within_merged_on_device_equal_the_unsharded_answer(hip_engine):
+    """isccsearch_search_within_device per shard + merge_kernel == isccsearch_search_within on the whole table;
+    the product ShardedTable (one rank, no process group) goes through the same device path."""
+    import torch
+
+    from iscc_search_amd.sharded import HipShardOps, ShardedTable, block_bytes
+
+    rng = np.random.default_rng(31)
+    n, nq = 50000, 9
+    words = rng.integers(0, 5, size=(n, 2), dtype=np.uint64) * np.uint64(0x1111111111111111)
+    keys = np.stack([rng.integers(1, 40, size=n).astype(np.uint64), rng.permutation(n).astype(np.uint64)], axis=1)
+    q = np.concatenate([words[:6], rng.integers(0, 2**64, size=(3, 2), dtype=np.uint64)])
+    whole = hip_engine.open_table(METRIC_HAMMING, 2, 16)
+    shards = [hip_engine.open_table(METRIC_HAMMING, 2, 16) for _ in range(2)]
+    try:
+        whole.add(keys, words)
+        shards[0].add(keys[: n // 3], words[: n // 3])
+        shards[1].add(keys[n // 3:], words[n // 3:])
+        for r, k in ((0, 1000), (0, 11), (4, 300), (128, 50)):
+            exp = whole.search_within(q, None, k, r)
+            rec_bytes, blk = block_bytes(nq, k)
+            gathered = torch.empty(2 * blk, dtype=torch.uint8, device="cuda:0")
+            for i, t in enumerate(shards):
+                base = gathered.data_ptr() + i * blk
+                t.search_device(q, None, k, base, base + rec_bytes, max_hamming=r)
+            torch.cuda.synchronize()
+            merged = hip_engine.merge_device(2, nq, k, 2, gathered.data_ptr(), gathered.data_ptr() + rec_bytes, blk, blk)
+            for a, b in zip(exp, merged):
+                np.testing.assert_array_equal(a, b)
+            one = ShardedTable(HipShardOps(whole, "cuda:0")).search_within(q, None, k, r)
+            for a, b in zip(exp, one):
+                np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ShardedTable(HipShardOps(whole, "cuda:0")).doc_freq(q, None, 1000), whole.doc_freq(q, None, 1000))
+    finally:
+        for t in shards + [whole]:
+            t.drop()

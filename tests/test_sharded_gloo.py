@@ -27,8 +27,8 @@ class OracleShardOps:
         self.table = table
         self.key_words = table.key_words
 
-    def local_search(self, q_words, q_nbytes, k):
-        rec, cnt = self.table.search_records(q_words, q_nbytes, k)
+    def local_search(self, q_words, q_nbytes, k, max_hamming=None):
+        rec, cnt = self.table.search_records(q_words, q_nbytes, k, max_hamming)
         nq = q_words.shape[0]
         rec_bytes, blk = block_bytes(nq, k)
         buf = np.zeros(blk, dtype=np.uint8)
@@ -105,6 +105,53 @@ def _worker(rank, world, port, metric, routing, out_dir):
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), *got)
     finally:
         dist.destroy_process_group()
+
+
+def _within_dataset():
+    """Simprint-style table: 128-bit keys (asset, chunk), few distinct 64-bit codes, assets spread over both shards."""
+    rng = np.random.default_rng(77)
+    n = 3000
+    words = rng.integers(0, 6, size=(n, 1), dtype=np.uint64) * np.uint64(0x0101010101010101)
+    keys = np.stack([rng.integers(1, 25, size=n).astype(np.uint64), rng.permutation(n).astype(np.uint64)], axis=1)
+    q = np.array([[0], [0x0303030303030303], [0x0303030303030302], [0x7777777777777777]], dtype=np.uint64)
+    return keys, words, q
+
+
+def _within_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys, words, q = _within_dataset()
+        lo, hi = shard_range(len(keys), rank, world)
+        table = OracleTable(0, 2, 8)
+        table.add(keys[lo:hi], words[lo:hi])
+        sharded = ShardedTable(OracleShardOps(table))
+        out = {}
+        for r, k in ((0, 1000), (0, 7), (1, 40), (9, 25)):
+            for i, a in enumerate(sharded.search_within(q, None, k, r)):
+                out[f"w_{r}_{k}_{i}"] = a
+        out["freq_1000"] = sharded.doc_freq(q, None, 1000)
+        out["freq_5"] = sharded.doc_freq(q, None, 5)
+        np.savez(os.path.join(out_dir, f"w{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_range_limited_search_and_doc_freq_equal_the_unsharded_table(tmp_path):
+    world = 2
+    mp.spawn(_within_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    keys, words, q = _within_dataset()
+    whole = OracleTable(0, 2, 8)
+    whole.add(keys, words)
+    for rank in range(world):
+        with np.load(os.path.join(tmp_path, f"w{rank}.npz")) as z:
+            for r, k in ((0, 1000), (0, 7), (1, 40), (9, 25)):
+                for i, e in enumerate(whole.search_within(q, None, k, r)):
+                    np.testing.assert_array_equal(z[f"w_{r}_{k}_{i}"], e, err_msg=f"rank {rank} r={r} k={k} field {i}")
+            np.testing.assert_array_equal(z["freq_1000"], whole.doc_freq(q, None, 1000))
+            np.testing.assert_array_equal(z["freq_5"], whole.doc_freq(q, None, 5))
+            assert z["freq_1000"][0] > 1 and z["freq_1000"][3] == 0
 
 
 def _free_port():
