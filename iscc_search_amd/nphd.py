@@ -275,7 +275,8 @@ def key128_to_words(keys):
 
 def words_to_key128(words):
     # type: (np.ndarray) -> list[bytes]
-    return [bytes(r) for r in np.ascontiguousarray(words, dtype=np.uint64).astype(">u8").view("V16").reshape(-1)]
+    raw = np.ascontiguousarray(words, dtype=np.uint64).astype(">u8").tobytes()
+    return [raw[i : i + 16] for i in range(0, len(raw), 16)]
 
 
 class HipIndex128:
@@ -353,6 +354,18 @@ class HipIndex128:
             c = int(cnt[q])
             out.append(Matches(words_to_key128(keys[q, :c]), ham[q, :c].astype(np.float32), ham[q, :c].copy(), pbits[q, :c].copy()))
         return out[0] if single else BatchMatches(out)
+
+    def search_arrays(self, vectors, count=10):
+        # type: (np.ndarray, int) -> tuple[np.ndarray, np.ndarray, np.ndarray]
+        """
+        The same search as raw arrays, for callers that filter before they materialise keys:
+        (key words uint64 [nq, count, 2], differing bits uint32 [nq, count], valid entries uint32 [nq]).
+        """
+        if count < 1:
+            raise ValueError("`count` must be >= 1")
+        q_words, _ = pack_bytes(self._vectors(vectors), self._table.max_words)
+        keys, ham, _, cnt = self._table.search(q_words, None, count)
+        return keys, ham, cnt
 
     def search_within(self, vectors, count, max_hamming=0):
         # type: (np.ndarray, int, int) -> Matches | BatchMatches

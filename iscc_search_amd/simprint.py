@@ -17,7 +17,7 @@ from typing import Callable, List, Optional
 import numpy as np
 
 from iscc_search_amd._lib import MAX_K
-from iscc_search_amd.nphd import HipIndex128
+from iscc_search_amd.nphd import HipIndex128, words_to_key128
 
 CHUNK_POINTER_BYTES = 16
 MAX_OFFSET = 2**32 - 1
@@ -143,21 +143,25 @@ class HipSimprintIndex:
             return []
         queries = np.stack([np.frombuffer(s, dtype=np.uint8) for s in simprints])
         count = min(MAX_K, max(1, limit * self.oversampling_factor))   # the engine's k ceiling (4096)
-        batch = self._index.search(queries, count=count)
+        key_words, ham, cnt = self._index.search_arrays(queries, count=count)
+
+        # Threshold first, on the whole [queries x count] block at once: the reference walks every neighbour in
+        # Python (usearch_core.py:175-196); most of an oversampled list fails the threshold.  Same arithmetic
+        # (float64 division of an exact integer), same visiting order (query, then rank) for the survivors.
+        scores = 1.0 - ham.astype(np.float64) / self.ndim
+        keep = (np.arange(ham.shape[1])[None, :] < cnt[:, None]) & (scores >= threshold)
+        q_of, pos_of = np.nonzero(keep)
+        raw_keys = words_to_key128(key_words[q_of, pos_of])
+        kept_scores = scores[q_of, pos_of].tolist()
 
         # best chunk per (asset, query simprint)
         asset_best = defaultdict(dict)
-        for qi in range(len(simprints)):
-            m = batch[qi]
-            for raw_key, distance in zip(m.keys, m.distances):
-                score = 1.0 - (float(distance) / self.ndim)
-                if score < threshold:
-                    continue
-                asset_id = raw_key[:8]
+        for qi, raw_key, score in zip(q_of.tolist(), raw_keys, kept_scores):
+            asset_id = raw_key[:8]
+            cur = asset_best[asset_id].get(qi)
+            if cur is None or score > cur[2]:
                 offset, size = struct.unpack("!II", raw_key[8:16])
-                cur = asset_best[asset_id].get(qi)
-                if cur is None or score > cur[2]:
-                    asset_best[asset_id][qi] = (offset, size, score, raw_key)
+                asset_best[asset_id][qi] = (offset, size, score, raw_key)
         if not asset_best:
             return []
 
