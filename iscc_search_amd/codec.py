@@ -109,6 +109,14 @@ def encode_header(mtype, stype, version=0, length=1):
 def decode_header(data):
     # type: (bytes) -> tuple[int, int, int, int, bytes]
     """(MainType, SubType, Version, Length, tail bytes)."""
+    if len(data) >= 2 and not (data[0] & 0x88) and not (data[1] & 0x88):
+        # every field below 8: four plain nibbles (all unit and ISCC-ID headers in use)
+        return data[0] >> 4, data[0] & 15, data[1] >> 4, data[1] & 15, bytes(data[2:])
+    return _decode_header_general(data)
+
+
+def _decode_header_general(data):
+    # type: (bytes) -> tuple[int, int, int, int, bytes]
     bits = "".join(format(b, "08b") for b in data)
     pos = 0
     vals = []
@@ -130,7 +138,9 @@ def decode_header(data):
         vals.append(int(bits[pos + pre : pos + width], 2) + off)
         pos += width
     rest = bits[pos:]
-    if len(rest) % 8 and rest[:4] == "0000":
+    if len(rest) % 8:
+        if rest[:4] != "0000":
+            raise ValueError("invalid ISCC header padding")
         rest = rest[4:]
     tail = int(rest, 2).to_bytes(len(rest) // 8, "big") if rest else b""
     return vals[0], vals[1], vals[2], vals[3], tail

@@ -42,6 +42,7 @@ for nq in (16, 64, 256):
             print(f"search_raw nq={nq} limit={limit*2} (count={limit*2*20}) {mode}{' [column built]' if built else ''}: "
                   f"{dt*1e3:8.2f} ms, {len(res)} assets, top score {res[0].score:.4f}")
         exact_q = [bytes(r) for r in first[:nq]]
+        idx.search_exact(exact_q, limit=limit * 2, threshold=0.0, detailed=True)     # first call grows the pinned result buffers
         t0 = time.perf_counter()
         res = idx.search_exact(exact_q, limit=limit * 2, threshold=0.0, detailed=True)
         print(f"search_exact nq={nq}: {(time.perf_counter() - t0)*1e3:8.2f} ms, {len(res)} assets")
