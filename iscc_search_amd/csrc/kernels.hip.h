@@ -54,6 +54,14 @@ static_assert(sizeof(Record) == 24, "record layout");
 // rows per thread per tile: every thread issues U 16-byte loads per column (2 rows each)
 template <int W> struct TileCfg { static constexpr int U = (W == 1) ? 4 : (W == 2 ? 2 : 1); };
 template <int W> constexpr int tile_rows() { return BLOCK * 2 * TileCfg<W>::U; }
+// Where the TQ queries of a group live while a block scans.
+//   SGPRs (scalar operands of v_xor, nothing to load in the loop) as long as they FIT: TQ*W*2 query dwords + TQ
+//   biases + the loop's own scalars must stay under ~100 registers, beyond that hipcc spills them into VGPR lanes
+//   and every use costs a v_readlane -- a VALU instruction, the very resource the kernel is short of (W=4, TQ=8:
+//   52 spilled SGPRs = +19 % VALU work per tile; TQ=16: 211).
+//   LDS otherwise: one broadcast ds_read_b128 per four query dwords per tile, on the LDS pipe, into VGPR operands.
+template <int W, int TQ> constexpr bool queries_in_lds() { return TQ * W >= 24; }
+template <int W> constexpr int query_vecs() { return (2 * W + 3) / 4; }   // u32x4 slots per query in LDS
 
 struct ScanParams {
     const uint64_t* col[4];   // segment columns (word-major)
@@ -182,21 +190,53 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
     static_assert(!FOLD || (W == 1 && !MASK), "the OR-fold filter is for whole 64-bit codes");
     constexpr int U = TileCfg<W>::U;
     constexpr int TILE = BLOCK * 2 * U;
+    constexpr bool QL = queries_in_lds<W, TQ>() && !FOLD;
+    constexpr int NV = query_vecs<W>();
     const uint32_t tid = threadIdx.x;
     const uint32_t q0 = blockIdx.y * TQ;
 
-    // queries and biases -> SGPRs (uniform addresses: scalar loads)
-    uint32_t qlo[TQ][W], qhi[TQ][W], bias[TQ];
+    // biases -> SGPRs; queries -> SGPRs (uniform addresses: scalar loads) or LDS (see queries_in_lds)
+    __shared__ u32x4 lq[QL ? TQ * NV : 1];
+    uint32_t qlo[QL ? 1 : TQ][W], qhi[QL ? 1 : TQ][W], bias[TQ];
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
         bias[q] = sgpr(p.bias[q0 + q]);
+        if constexpr (!QL) {
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const uint64_t v = p.queries[(uint64_t)(q0 + q) * 4 + w];
-            qlo[q][w] = sgpr((uint32_t)v);
-            qhi[q][w] = sgpr((uint32_t)(v >> 32));
+            for (int w = 0; w < W; ++w) {
+                const uint64_t v = p.queries[(uint64_t)(q0 + q) * 4 + w];
+                qlo[q][w] = sgpr((uint32_t)v);
+                qhi[q][w] = sgpr((uint32_t)(v >> 32));
+            }
         }
     }
+    if constexpr (QL) {
+        // dword d of query q = half (d & 1) of word d / 2; slots past 2*W stay zero
+        uint32_t* l = reinterpret_cast<uint32_t*>(lq);
+        for (uint32_t i = tid; i < (uint32_t)(TQ * NV * 4); i += BLOCK) {
+            const uint32_t q = i / (NV * 4), d = i % (NV * 4);
+            uint32_t val = 0;
+            if (d < 2 * W) {
+                const uint64_t v = p.queries[(uint64_t)(q0 + q) * 4 + d / 2];
+                val = (d & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
+            }
+            l[i] = val;
+        }
+        __syncthreads();
+    }
+    // the words of query q as operands: SGPR copies, or one broadcast LDS read per four dwords
+    auto query_words = [&](int q, uint32_t (&ql)[W], uint32_t (&qh)[W]) {
+        if constexpr (QL) {
+            u32x4 t[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) t[j] = lq[q * NV + j];
+#pragma unroll
+            for (int w = 0; w < W; ++w) { ql[w] = t[(2 * w) / 4][(2 * w) % 4]; qh[w] = t[(2 * w + 1) / 4][(2 * w + 1) % 4]; }
+        } else {
+#pragma unroll
+            for (int w = 0; w < W; ++w) { ql[w] = qlo[q][w]; qh[w] = qhi[q][w]; }
+        }
+    };
     const uint32_t mlo = sgpr(p.mask_lo), mhi = sgpr(p.mask_hi);
 
     const uint64_t n_full = p.n_rows / TILE;
@@ -222,6 +262,8 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < TQ; ++q) {
+            uint32_t ql[W], qh[W];
+            query_words(q, ql, qh);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t a0, a1;
@@ -231,8 +273,8 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                     // v_bcnt per row: 3.5 VALU ops per pair instead of 4.5.  For unrelated codes y is 3/4 ones
                     // (popc ~ 24 +- 2.4), so at tau ~ 12-15 the filter passes ~1e-5 of the pairs; the exact
                     // distance is computed in the emit path below.
-                    const uint32_t y0 = __builtin_amdgcn_bitop3_b32(v[u][0].x ^ qlo[q][0], v[u][0].y, qhi[q][0], 0xF6);
-                    const uint32_t y1 = __builtin_amdgcn_bitop3_b32(v[u][0].z ^ qlo[q][0], v[u][0].w, qhi[q][0], 0xF6);
+                    const uint32_t y0 = __builtin_amdgcn_bitop3_b32(v[u][0].x ^ ql[0], v[u][0].y, qh[0], 0xF6);
+                    const uint32_t y1 = __builtin_amdgcn_bitop3_b32(v[u][0].z ^ ql[0], v[u][0].w, qh[0], 0xF6);
                     a0 = (uint32_t)__builtin_popcount(y0) + bias[q];   // one v_bcnt_u32_b32 with the SGPR bias as accumulator
                     a1 = (uint32_t)__builtin_popcount(y1) + bias[q];
                     m = min3u(m, a0, a1);
@@ -240,8 +282,8 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                 }
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    uint32_t x0 = v[u][w].x ^ qlo[q][w], y0 = v[u][w].y ^ qhi[q][w];
-                    uint32_t x1 = v[u][w].z ^ qlo[q][w], y1 = v[u][w].w ^ qhi[q][w];
+                    uint32_t x0 = v[u][w].x ^ ql[w], y0 = v[u][w].y ^ qh[w];
+                    uint32_t x1 = v[u][w].z ^ ql[w], y1 = v[u][w].w ^ qh[w];
                     if (MASK && w == W - 1) { x0 &= mlo; y0 &= mhi; x1 &= mlo; y1 &= mhi; }
                     if (w == 0) { a0 = bcnt_s(x0, bias[q]); a1 = bcnt_s(x1, bias[q]); }
                     else { a0 = bcnt_v(x0, a0); a1 = bcnt_v(x1, a1); }
@@ -268,13 +310,15 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
             for (int q = 0; q < TQ; ++q) {
                 uint32_t a[U][2];
                 uint32_t mq = 0xFFFFFFFFu;
+                uint32_t ql[W], qh[W];
+                query_words(q, ql, qh);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     uint32_t a0 = bias[q], a1 = bias[q];
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
-                        uint32_t x0 = r[u][w].x ^ qlo[q][w], y0 = r[u][w].y ^ qhi[q][w];
-                        uint32_t x1 = r[u][w].z ^ qlo[q][w], y1 = r[u][w].w ^ qhi[q][w];
+                        uint32_t x0 = r[u][w].x ^ ql[w], y0 = r[u][w].y ^ qh[w];
+                        uint32_t x1 = r[u][w].z ^ ql[w], y1 = r[u][w].w ^ qh[w];
                         if (MASK && w == W - 1) { x0 &= mlo; y0 &= mhi; x1 &= mlo; y1 &= mhi; }
                         a0 = bcnt(y0, bcnt(x0, a0));
                         a1 = bcnt(y1, bcnt(x1, a1));
