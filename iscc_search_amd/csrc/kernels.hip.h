@@ -62,6 +62,11 @@ template <int W> constexpr int tile_rows() { return BLOCK * 2 * TileCfg<W>::U; }
 //   LDS otherwise: one broadcast ds_read_b128 per four query dwords per tile, on the LDS pipe, into VGPR operands.
 template <int W, int TQ> constexpr bool queries_in_lds() { return TQ * W >= 24; }
 template <int W> constexpr int query_vecs() { return (2 * W + 3) / 4; }   // u32x4 slots per query in LDS
+// tiles in flight ahead of the one being scored (experiment switch; 1 = double buffering)
+#ifndef ISK_PREFETCH_DEPTH_W1
+#define ISK_PREFETCH_DEPTH_W1 1
+#endif
+template <int W> constexpr int prefetch_depth() { return W == 1 ? ISK_PREFETCH_DEPTH_W1 : 1; }
 
 struct ScanParams {
     const uint64_t* col[4];   // segment columns (word-major)
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
     // U*W younger loads are outstanding at every wait: s_waitcnt vmcnt(U*W) retires the current tile
     // and leaves the prefetch alone.  (The rare emit path may add compiler-counted stores/atomics in
     // between; more outstanding operations only make the counted wait stricter, never weaker.)
-    {
+    if constexpr (prefetch_depth<W>() == 1) {
         u32x4 va[U][W], vb[U][W];
         uint64_t tile = p.row_begin / TILE + blockIdx.x;
         if (tile < n_full) {
@@ -363,6 +368,34 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                 tile = t2;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) prefetch
+        }
+    } else {
+        // two tiles ahead: three buffers rotate, 2*U*W younger loads are outstanding at every wait
+        static_assert(prefetch_depth<W>() == 2, "prefetch depth");
+        u32x4 va[U][W], vb[U][W], vc[U][W];
+        uint64_t t = p.row_begin / TILE + blockIdx.x;
+        const uint64_t G = gridDim.x;
+        if (t < n_full) {
+            const uint64_t last = n_full - 1;
+            auto clamp = [&](uint64_t x) { return x < n_full ? x : last; };
+            load_tile(va, t);
+            load_tile(vb, clamp(t + G));
+            for (;;) {
+                load_tile(vc, clamp(t + 2 * G));
+                wait_tile<2 * U * W>(va);
+                process(va, t);
+                if (t + G >= n_full) break;
+                load_tile(va, clamp(t + 3 * G));
+                wait_tile<2 * U * W>(vb);
+                process(vb, t + G);
+                if (t + 2 * G >= n_full) break;
+                load_tile(vb, clamp(t + 4 * G));
+                wait_tile<2 * U * W>(vc);
+                process(vc, t + 2 * G);
+                if (t + 3 * G >= n_full) break;
+                t += 3 * G;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused prefetches
         }
     }
 
