@@ -253,17 +253,27 @@ int ensure_index(H* h, Table& t) {
 // ------------------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------------------
-bool g_fold = false;  // experimental OR-fold filter for 64-bit codes (option "fold"; process-wide; off: see DESIGN.md section 4)
+bool g_fold = false;  // OR-fold filter + progressive threshold for the streaming pass over whole 64-bit codes
+                      // (option "fold"; process-wide)
 
 template <int W, bool MASK, int TQ, int MODE>
 void launch_scan_nt(bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     // only the non-temporal variant is instantiated: plain loads measured no faster and
     // every extra variant costs build time
     (void)nt;
-    if constexpr (W == 1 && !MASK) {
-        if (g_fold) { hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true, true>), grid, dim3(isk::BLOCK), 0, st, p); return; }
-    }
     hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true>), grid, dim3(isk::BLOCK), 0, st, p);
+}
+// the streaming pass over whole 64-bit codes with the folded fast path under a progressively tightened threshold
+#ifndef ISK_EXP_FOLD
+#define ISK_EXP_FOLD true
+#endif
+void launch_scan_fold(int tq, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    switch (tq) {
+        case 8: hipLaunchKernelGGL((isk::scan_kernel<1, false, 8, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
+        case 10: hipLaunchKernelGGL((isk::scan_kernel<1, false, 10, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
+        case 12: hipLaunchKernelGGL((isk::scan_kernel<1, false, 12, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
+        default: hipLaunchKernelGGL((isk::scan_kernel<1, false, 16, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
+    }
 }
 template <int W, bool MASK, int TQ>
 void launch_scan_mode(int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
@@ -375,7 +385,7 @@ struct Batch {
         Ctx c{};
         for (uint32_t w = 0; w < j.W; ++w) c.sp.col[w] = s.col[w];
         c.sp.queries = h->d_queries.p; c.sp.bias = h->d_bias.p; c.sp.cnt = h->d_cnt.p; c.sp.cand = h->d_cand.p;
-        c.sp.ghist = h->d_ghist.p; c.sp.cap = cap;
+        c.sp.ghist = h->d_ghist.p; c.sp.cap = cap; c.sp.k = k;
         c.sp.mask_lo = (uint32_t)j.mask_last; c.sp.mask_hi = (uint32_t)(j.mask_last >> 32);
         c.sl.cnt = h->d_cnt.p; c.sl.cand = h->d_cand.p; c.sl.cap = cap; c.sl.keys = s.keys;
         c.sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
@@ -483,6 +493,7 @@ struct Batch {
             const uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;
             HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
             uint64_t collected_to = 0;            // rows [0, collected_to) already have their candidates appended
+            bool hist_live = false;               // d_ghist holds the histogram of exactly those rows
             sp.row_begin = 0;
             for (uint64_t sample = s0; sample < s_last;) {
                 sample = std::min<uint64_t>(s_last, sample * growth);
@@ -494,7 +505,7 @@ struct Batch {
                 isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, sample)};
                 hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
                 h->stats.sample_bytes += sample * 8 * j.W * groups;
-                if (last) collected_to = sample;
+                if (last) { collected_to = sample; hist_live = true; }
             }
 
             // 3. the streaming pass: collect every remaining row within the threshold
@@ -504,7 +515,13 @@ struct Batch {
                 const uint64_t rows = s.n - collected_to;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
-                launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                if (g_fold && j.W == 1 && !j.mask) {
+                    // folded fast path + progressive threshold; the histogram it keeps must cover the rows collected so far
+                    if (!hist_live) HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
+                    launch_scan_fold(tq, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                } else {
+                    launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                }
                 if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
                 h->stats.scan_launches += 1;
                 h->stats.scan_passes += groups;

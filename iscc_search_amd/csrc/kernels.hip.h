@@ -73,12 +73,13 @@ struct ScanParams {
     uint64_t row_begin;       // first row scanned (a multiple of the tile size)
     uint64_t n_rows;          // rows [row_begin, n_rows) are scanned
     const uint64_t* queries;  // [nq_pad][4] big-endian packed query words
-    const uint32_t* bias;     // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries)
+    uint32_t* bias;           // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries); PROG scans tighten it
     uint32_t* cnt;            // [nq_pad * CNT_STRIDE] candidates appended so far (MODE_COLLECT)
     uint64_t* cand;           // [nq_pad][cap] (hamming << 48) | row          (MODE_COLLECT)
     uint32_t* ghist;          // [nq_pad][HB] histogram of hamming <= tau     (MODE_HIST)
     uint32_t cap;
     uint32_t mask_lo, mask_hi;  // mask of the last compared word (partial-word prefixes)
+    uint32_t k;                 // results wanted per query (PROG scans: the threshold follows the k-th best so far)
 };
 
 __device__ __forceinline__ uint32_t bcnt(uint32_t x, uint32_t acc) {
@@ -173,13 +174,39 @@ __device__ __forceinline__ void wait_tile(u32x4 (&v)[U][W]) {
         for (int w = 0; w < W; ++w) asm volatile("" : "+v"(v[u][w]));
 }
 
+// returns the candidate's slot in the query's list (0 in MODE_HIST)
 template <int MODE>
-__device__ __forceinline__ void emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
+__device__ __forceinline__ uint32_t emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
+    uint32_t slot = 0;
     if constexpr (MODE == MODE_COLLECT || MODE == MODE_BOTH) {
-        const uint32_t slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
+        slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
         if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)h << 48) | row;
     }
     if constexpr (MODE == MODE_HIST || MODE == MODE_BOTH) atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
+    return slot;
+}
+
+// Progressive threshold (PROG scans): ghist[q] counts every row seen so far per distance and is complete for all
+// bins <= the current tau (tau only ever decreases).  Once the bins 0..t hold k rows for some t < tau, no row
+// further than t can reach the top k: publish the tighter threshold.  Called by lanes that just appended a
+// candidate (rare), so the <= tau loads do not matter.
+__device__ __forceinline__ void tighten(const ScanParams& p, uint32_t qi, uint32_t bias_now) {
+    const uint32_t tau = 0x7FFFFFFFu - bias_now;       // <= 64: PROG scans cover whole 64-bit codes only
+    const uint32_t* hq = p.ghist + (uint64_t)qi * HB;
+    uint32_t cum = 0;
+    for (uint32_t base = 0; base < tau; base += 16) {
+        // sixteen bins per round trip: the loads bypass the caches (agent scope), one dependent load per bin
+        // would stall the wave for ~tau memory latencies
+        uint32_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(hq + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (base + i >= tau) return;
+            cum += v[i];
+            if (cum >= p.k) { atomicMax(&p.bias[qi], 0x7FFFFFFFu - (base + i)); return; }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -190,9 +217,14 @@ __device__ __forceinline__ void emit(const ScanParams& p, uint32_t qi, uint32_t 
 //   so acc < 2^31  <=>  hamming <= tau_q, and one v_min3 folds two rows into the lane's running
 //   minimum.  Only lanes whose minimum has bit 31 clear enter the (rare) emit path.
 // ---------------------------------------------------------------------------------------------
-template <int W, bool MASK, int TQ, int MODE, bool NT, bool FOLD = false>
+//   FOLD: the fast path tests popc((lo^q_lo)|(hi^q_hi)) <= tau, a NECESSARY condition, for 3.5 instead of 4.5 ops
+//         per pair; the emit path computes the exact distance.  Only pays under a tight threshold, hence
+//   PROG: the SGPR thresholds are refreshed from p.bias every two tiles while emitters tighten p.bias to the
+//         k-th best distance seen so far (MODE_BOTH: the histogram is the bookkeeping).
+template <int W, bool MASK, int TQ, int MODE, bool NT, bool FOLD = false, bool PROG = false>
 __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
     static_assert(!FOLD || (W == 1 && !MASK), "the OR-fold filter is for whole 64-bit codes");
+    static_assert(!PROG || MODE == MODE_BOTH, "the progressive threshold needs the candidate histogram");
     constexpr int U = TileCfg<W>::U;
     constexpr int TILE = BLOCK * 2 * U;
     constexpr bool QL = queries_in_lds<W, TQ>() && !FOLD;
@@ -332,12 +364,14 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                     mq = min(mq, min(a0, a1));
                 }
                 if ((int32_t)mq >= 0) {
+                    bool look = false;     // PROG: every 8th candidate of a query re-derives the threshold
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const uint64_t row = base + (uint64_t)u * 128;
-                        if ((int32_t)a[u][0] >= 0) emit<MODE>(p, q0 + q, a[u][0] - bias[q], row);
-                        if ((int32_t)a[u][1] >= 0) emit<MODE>(p, q0 + q, a[u][1] - bias[q], row + 1);
+                        if ((int32_t)a[u][0] >= 0) look |= (emit<MODE>(p, q0 + q, a[u][0] - bias[q], row) & 7u) == 7u;
+                        if ((int32_t)a[u][1] >= 0) look |= (emit<MODE>(p, q0 + q, a[u][1] - bias[q], row + 1) & 7u) == 7u;
                     }
+                    if constexpr (PROG) { if (look) tighten(p, q0 + q, bias[q]); }
                 }
             }
         }
@@ -355,10 +389,18 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
             const uint64_t last = n_full - 1;
             load_tile(va, tile);
             for (;;) {
+                // PROG: fetch the live thresholds (agent scope: past the CU's L1) BEFORE the prefetch is issued, so
+                // the counted wait below still sees exactly U*W younger loads; consumed after the tile is scored
+                uint32_t live = 0;
+                if constexpr (PROG) live = __hip_atomic_load(&p.bias[q0 + lane % TQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint64_t t1 = tile + gridDim.x;
                 load_tile(vb, t1 < n_full ? t1 : last);
                 wait_tile<U * W>(va);
                 process(va, tile);
+                if constexpr (PROG) {
+#pragma unroll
+                    for (int q = 0; q < TQ; ++q) bias[q] = __builtin_amdgcn_readlane(live, q);
+                }
                 if (t1 >= n_full) break;
                 const uint64_t t2 = t1 + gridDim.x;
                 load_tile(va, t2 < n_full ? t2 : last);

@@ -36,5 +36,9 @@ def hip_engine():
     from iscc_search_amd.engine import HipEngine
 
     eng = HipEngine(0)
+    # ISCC_HIP_OPTS="fold=1,queries_per_pass=16": run the whole GPU tier under non-default engine options
+    for item in filter(None, os.environ.get("ISCC_HIP_OPTS", "").split(",")):
+        name, value = item.split("=")
+        eng.set_option(name.strip(), int(value))
     yield eng
     eng.close()
