@@ -423,7 +423,7 @@ struct Batch {
         }
         cap = std::max<uint32_t>(16384, 8 * k);
         multi = jobs.size() > 1;
-        P = next_pow2(k);
+        P = next_pow2(std::max<uint32_t>(k, 1024));   // select's LDS sort buffer: room for small tie classes (12-20 KB)
         sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
         int rc;
         if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;

@@ -657,10 +657,13 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
     uint32_t r = keff - less;            // 1 <= r <= tie
     __syncthreads();
 
-    // 2. radix select on the key inside the tie class
+    // 2. radix select on the key inside the tie class -- skipped when everything up to and including the tie
+    //    class fits the sort buffer (the usual case: a few dozen rows): the sort then orders the ties by key and
+    //    the first keff entries are the answer, without up to 8*KW dependent passes over the gathered keys
     uint64_t phi = 0, plo = 0;           // selected key prefix (first d bytes)
     int d = 0;
-    while (r < tie && d < KW * 8) {
+    const bool fits = less + tie <= P;
+    while (!fits && r < tie && d < KW * 8) {
         for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < total; i += BLOCK) {
