@@ -213,7 +213,8 @@ def main():
             "launches": st["scan_launches"],
             "avg_launch_ms": (st["scan_ms"] / st["scan_launches"]) if st["scan_launches"] else None,
             "algorithmic_bytes_per_launch": (st["scan_bytes"] / st["scan_launches"]) if st["scan_launches"] else None,
-            "measured_copy_ceiling_GBs": 6290.0,
+            "measured_copy_ceiling_GBs": 6290.0,          # MI355X_MICROARCH.md: measured streaming copy
+            "measured_read_ceiling_GBs": 7050.0,          # profiles/r01_micro_read.txt: pure nontemporal read, same device
         },
         "whole_step_GBs": (st["scan_bytes"] / 1e9) / elapsed,
         "fallback_queries": st["fallback_queries"],
