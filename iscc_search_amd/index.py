@@ -164,6 +164,8 @@ class HipIndex:
                     unit_map[unit.unit_type] = unit.body   # same type at two lengths: last one wins (:423-430)
                 sp_decoded = {}
                 for sp_type, sp_list in (asset.simprints or {}).items():
+                    if not sp_list:
+                        continue           # a type listed without chunks indexes nothing
                     sp_decoded[sp_type] = [(codec.decode_base64(sp.simprint), pack_chunk_pointer(id_obj.body, sp.offset, sp.size)) for sp in sp_list]
                 staged.append((key, id_obj.body, stored, unit_map, sp_decoded))
 

@@ -162,3 +162,9 @@ def test_exact_mode_through_index(manager):
     manager.add_assets("sp", [make_asset(rng, 2, simprints={"CONTENT_TEXT_V0": [sp(b"\xcc" * 8, 5, 6)]})])
     assert [m.iscc_id for m in _exact(manager, {"CONTENT_TEXT_V0": [sp(a).simprint]}).chunk_matches] == [ids[0]]
     assert [m.iscc_id for m in _exact(manager, {"CONTENT_TEXT_V0": [sp(b"\xcc" * 8).simprint]}).chunk_matches] == [ids[1]]
+
+
+def test_empty_simprint_list_indexes_nothing(manager):
+    rng = np.random.default_rng(6)
+    manager.add_assets("sp", [make_asset(rng, 9, simprints={"CONTENT_TEXT_V0": []})])
+    assert _exact(manager, {"CONTENT_TEXT_V0": [sp(b"\xaa" * 8).simprint]}).chunk_matches == []
