@@ -323,9 +323,12 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                     uint32_t x1 = v[u][w].z ^ ql[w], y1 = v[u][w].w ^ qh[w];
                     if (MASK && w == W - 1) { x0 &= mlo; y0 &= mhi; x1 &= mlo; y1 &= mhi; }
                     if (w == 0) { a0 = bcnt_s(x0, bias[q]); a1 = bcnt_s(x1, bias[q]); }
-                    else { a0 = bcnt_v(x0, a0); a1 = bcnt_v(x1, a1); }
+                    else { a0 = pin(bcnt_v(x0, a0)); a1 = pin(bcnt_v(x1, a1)); }
                     a0 = bcnt_v(y0, a0);
                     a1 = bcnt_v(y1, a1);
+                    // multi-word codes: every step of the chain is pinned, or hipcc re-associates the words after the
+                    // first into v_bcnt(x, 0) + v_bcnt(y, 0) + v_add3 (W = 4: 48 extra VALU instructions per wave-tile)
+                    if (W > 1 && w + 1 < W) { a0 = pin(a0); a1 = pin(a1); }
                 }
                 m = min3u(m, a0, a1);
             }
