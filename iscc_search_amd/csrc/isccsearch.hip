@@ -154,6 +154,9 @@ struct isccsearch_handle {
     DevBuf<isk::Record> d_lists, d_final;
     PinBuf<uint64_t> p_queries;     // pinned staging: queries in, flags / results out
     PinBuf<uint32_t> p_flags, p_cnt;
+    // one batch's results as ONE block {records [m][k] | counts [m] | overflow flags}: a single device->host copy
+    DevBuf<unsigned char> d_block;
+    PinBuf<unsigned char> p_block;
     PinBuf<isk::Record> p_final;
     DevBuf<uint64_t> d_misc;        // moves / gather rows / single query
     DevBuf<uint64_t> d_misc2;
@@ -370,6 +373,8 @@ struct Batch {
     uint32_t* d_out_cnt;      // [nq]     device
     int tq = 8;
     int radius = -1;          // >= 0: report only rows within this Hamming distance (fixed threshold, no sampling)
+    uint32_t* d_flags = nullptr;        // overflow flags [jobs][nq_pad]; the caller may place them inside its result block
+    const uint32_t* h_flags = nullptr;  // where the host finds them after the copy (default: h->p_flags)
     uint32_t nq_pad = 0, groups = 0, cap = 0, P = 0;
     size_t sel_lds = 0;
     bool multi = false;
@@ -391,7 +396,7 @@ struct Batch {
         c.sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
         c.sl.out = multi ? h->d_lists.p + ji * (size_t)nq * k : d_out;
         c.sl.out_count = multi ? h->d_listcnt.p + ji * (size_t)nq : d_out_cnt;
-        c.sl.overflow = h->d_overflow.p + ji * (size_t)nq_pad;
+        c.sl.overflow = d_flags + ji * (size_t)nq_pad;
         c.sl.k = k; c.sl.P = P; c.sl.prefix_bits = j.pbytes * 8; c.sl.q_base = 0;
         return c;
     }
@@ -430,7 +435,10 @@ struct Batch {
         if ((rc = h->d_bias.ensure(nq_pad))) return rc;
         if ((rc = h->d_cnt.ensure((size_t)nq_pad * isk::CNT_STRIDE))) return rc;
         if ((rc = h->d_ghist.ensure((size_t)nq_pad * isk::HB))) return rc;
-        if ((rc = h->d_overflow.ensure(flag_words()))) return rc;
+        if (!d_flags) {
+            if ((rc = h->d_overflow.ensure(flag_words()))) return rc;
+            d_flags = h->d_overflow.p;
+        }
         if ((rc = h->d_cand.ensure((size_t)nq_pad * cap))) return rc;
         if (multi) {
             if ((rc = h->d_lists.ensure(jobs.size() * (size_t)nq * k))) return rc;
@@ -442,7 +450,6 @@ struct Batch {
         for (uint32_t q = 0; q < nq; ++q)
             for (int w = 0; w < t.max_words; ++w) h->p_queries.p[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
         HIPOK(hipMemcpyAsync(h->d_queries.p, h->p_queries.p, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPOK(hipMemsetAsync(h->d_overflow.p, 0, flag_words() * sizeof(uint32_t), h->stream));
 
         for (size_t ji = 0; ji < jobs.size(); ++ji) {
             const Job& j = jobs[ji];
@@ -452,10 +459,8 @@ struct Batch {
 
             if (radius >= 0) {
                 // range-limited search: the threshold is given, so one streaming pass collects everything
-                HIPOK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_bias.p), (int)(0x7FFFFFFFu - (uint32_t)radius), nq, h->stream));
-                if (nq_pad > nq)
-                    HIPOK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_bias.p + nq), (int)isk::BIAS_NEVER, nq_pad - nq, h->stream));
-                HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
+                hipLaunchKernelGGL(isk::radius_init_kernel, dim3((nq_pad + isk::BLOCK - 1) / isk::BLOCK), dim3(isk::BLOCK), 0, h->stream,
+                                   h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)radius);
                 sp.row_begin = 0;
                 sp.n_rows = s.n;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -474,7 +479,7 @@ struct Batch {
             const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
             isk::BootParams bp{};
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
-            bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
+            bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.cnt = h->d_cnt.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
             hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
 
             // 2. sample scans: tighten the threshold level by level.  A scan of S rows under the threshold
@@ -490,8 +495,7 @@ struct Batch {
             // boundary on a tile edge; a sample that covers the whole segment leaves nothing to stream
             if (s_last < s.n) s_last = s_last / tile_rows * tile_rows;
             if (s_last + tile_rows > s.n) s_last = s.n;
-            const uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;
-            HIPOK(hipMemsetAsync(h->d_cnt.p, 0, (size_t)nq_pad * isk::CNT_STRIDE * sizeof(uint32_t), h->stream));
+            const uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;      // (boot_kernel zeroed the candidate counters)
             uint64_t collected_to = 0;            // rows [0, collected_to) already have their candidates appended
             bool hist_live = false;               // d_ghist holds the histogram of exactly those rows
             sp.row_begin = 0;
@@ -540,11 +544,15 @@ struct Batch {
         if (jobs.empty()) return 0;
         int rc;
         if ((rc = h->p_flags.ensure(flag_words()))) return rc;
-        HIPOK(hipMemcpyAsync(h->p_flags.p, h->d_overflow.p, flag_words() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipMemcpyAsync(h->p_flags.p, d_flags, flag_words() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        h_flags = h->p_flags.p;
         return 0;
     }
+    // flags of the padding queries are never written: look at the real ones only
+    bool flagged(size_t ji, uint32_t q) const { return h_flags[ji * nq_pad + q] != 0; }
     bool any_flag() const {
-        for (size_t i = 0; i < flag_words(); ++i) if (h->p_flags.p[i]) return true;
+        for (size_t ji = 0; ji < jobs.size(); ++ji)
+            for (uint32_t q = 0; q < nq; ++q) if (flagged(ji, q)) return true;
         return false;
     }
 
@@ -556,7 +564,7 @@ struct Batch {
             const Job& j = jobs[ji];
             Segment& s = *j.seg;
             for (uint32_t q = 0; q < nq; ++q) {
-                if (!h->p_flags.p[ji * nq_pad + q]) continue;
+                if (!flagged(ji, q)) continue;
                 Ctx c = make_ctx(ji);
                 h->stats.fallback_queries += 1;
                 if ((rc = h->d_misc.ensure(isk::HB + 256 + 16))) return rc;   // full histogram + one key-byte histogram
@@ -749,6 +757,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         h->d_overflow.release(); h->d_listcnt.release(); h->d_outcnt.release(); h->d_cand.release();
         h->d_lists.release(); h->d_final.release(); h->d_misc.release(); h->d_misc2.release();
         h->p_queries.release(); h->p_flags.release(); h->p_cnt.release(); h->p_final.release();
+        h->d_block.release(); h->p_block.release();
         if (h->d_rank) (void)hipFree(h->d_rank);
         for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1242,25 +1251,35 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         hq.resize((size_t)m * t.max_words);
         for (uint32_t i = 0; i < m; ++i)
             memcpy(&hq[(size_t)i * t.max_words], q_words + (size_t)order[pos + i] * t.max_words, (size_t)t.max_words * 8);
-        if ((rc = h->d_final.ensure((size_t)m * k))) return rc;
-        if ((rc = h->d_outcnt.ensure(m))) return rc;
-        if ((rc = h->p_final.ensure((size_t)m * k))) return rc;
-        if ((rc = h->p_cnt.ensure(m))) return rc;
-        Batch batch(h, t, m, len, k, h->d_final.p, h->d_outcnt.p);
+        // result block {records [m][k] | counts [m] | flags [<= m + 15]} on the device and, mirrored, in pinned memory
+        const size_t rec_bytes = (size_t)m * k * sizeof(isk::Record);
+        const size_t flag_slots = (size_t)m + 16;                       // nq_pad <= m + 15 for every T_q
+        const size_t block_bytes = rec_bytes + ((size_t)m + flag_slots) * sizeof(uint32_t);
+        if ((rc = h->d_block.ensure(block_bytes))) return rc;
+        if ((rc = h->p_block.ensure(block_bytes))) return rc;
+        isk::Record* const d_rec = reinterpret_cast<isk::Record*>(h->d_block.p);
+        uint32_t* const d_cnt = reinterpret_cast<uint32_t*>(h->d_block.p + rec_bytes);
+        const isk::Record* const p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p);
+        uint32_t* const p_cnt = reinterpret_cast<uint32_t*>(h->p_block.p + rec_bytes);
+        uint32_t segments = 0;
+        for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) segments += t.seg[b].n ? 1 : 0;
+        Batch batch(h, t, m, len, k, d_rec, d_cnt);
         batch.radius = radius;
+        const bool one_copy = segments == 1 && !out_freq;   // flags ride in the block: results leave in ONE copy
+        if (one_copy) { batch.d_flags = d_cnt + m; batch.h_flags = p_cnt + m; }
         auto copy_results = [&]() -> int {
             if (out_freq) {
                 // only the distinct-asset count of every list leaves the device
                 int rf;
                 if ((rf = h->d_freq.ensure(m))) return rf;
-                isk::DistinctParams dp{h->d_final.p, h->d_outcnt.p, h->d_freq.p, k, (uint32_t)t.key_words};
+                isk::DistinctParams dp{d_rec, d_cnt, h->d_freq.p, k, (uint32_t)t.key_words};
                 hipLaunchKernelGGL(isk::distinct_kernel, dim3(m), dim3(isk::BLOCK), 0, h->stream, dp);
                 HIPOK(hipGetLastError());
-                HIPOK(hipMemcpyAsync(h->p_cnt.p, h->d_freq.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                HIPOK(hipMemcpyAsync(p_cnt, h->d_freq.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
                 return 0;
             }
-            HIPOK(hipMemcpyAsync(h->p_final.p, h->d_final.p, (size_t)m * k * sizeof(isk::Record), hipMemcpyDeviceToHost, h->stream));
-            HIPOK(hipMemcpyAsync(h->p_cnt.p, h->d_outcnt.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            const size_t bytes = rec_bytes + (size_t)m * sizeof(uint32_t) + (one_copy ? batch.flag_words() * sizeof(uint32_t) : 0);
+            HIPOK(hipMemcpyAsync(h->p_block.p, h->d_block.p, bytes, hipMemcpyDeviceToHost, h->stream));
             return 0;
         };
         if ((rc = batch.begin(hq.data()))) return rc;
@@ -1273,8 +1292,8 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             if ((rc = copy_results())) return rc;
             HIPOK(hipStreamSynchronize(h->stream));
         } else {
-            // one segment: flags and results travel together, ONE synchronisation per batch
-            if ((rc = batch.copy_flags())) return rc;
+            // one segment: flags and results travel together, ONE copy and ONE synchronisation per batch
+            if (!one_copy && (rc = batch.copy_flags())) return rc;
             if ((rc = copy_results())) return rc;
             HIPOK(hipStreamSynchronize(h->stream));
             if (!batch.jobs.empty() && batch.any_flag()) {
@@ -1285,9 +1304,9 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         }
         if (out_freq) {
             if (batch.jobs.empty()) for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = 0;
-            else for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = h->p_cnt.p[i];
+            else for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = p_cnt[i];
         } else {
-            unpack_records(h->p_final.p, h->p_cnt.p, m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
+            unpack_records(p_rec, p_cnt, m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
         }
         pos = end;
     }

@@ -514,10 +514,19 @@ __device__ __forceinline__ void block_find_cut(const uint32_t* hist, uint32_t nb
     __syncthreads();
 }
 
+// range-limited searches have a given threshold: one launch sets every bias and zeroes the candidate counters
+__global__ __launch_bounds__(BLOCK) void radius_init_kernel(uint32_t* bias, uint32_t* cnt, uint32_t nq, uint32_t nq_pad, uint32_t value) {
+    const uint32_t q = blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= nq_pad) return;
+    bias[q] = q < nq ? value : BIAS_NEVER;
+    cnt[(uint64_t)q * CNT_STRIDE] = 0;
+}
+
 struct BootParams {
     const uint64_t* col[4];
     const uint64_t* queries;  // [nq_pad][4]
     uint32_t* bias;           // [nq_pad] out
+    uint32_t* cnt;            // [nq_pad * CNT_STRIDE] candidate counters: zeroed here (saves the host a memset)
     uint64_t s0;              // rows [0, s0) are sampled (s0 >= 1)
     uint32_t nq;              // real queries; blocks q >= nq write BIAS_NEVER
     uint32_t k;
@@ -530,6 +539,7 @@ __global__ __launch_bounds__(BLOCK) void boot_kernel(const BootParams p) {
     __shared__ uint32_t hist[320];
     __shared__ uint32_t res[2];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) p.cnt[(uint64_t)q * CNT_STRIDE] = 0;
     if (q >= p.nq) {
         if (tid == 0) p.bias[q] = BIAS_NEVER;
         return;
@@ -637,8 +647,9 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t q = p.q_base + blockIdx.x;
     const uint32_t total = p.cnt[(uint64_t)q * CNT_STRIDE];
+    if (tid == 0) p.overflow[q] = total > p.cap ? 1u : 0u;   // always written: the host never has to clear the flags
     if (total > p.cap) {             // candidate list overflowed: host reruns this query exactly
-        if (tid == 0) { p.overflow[q] = 1; p.out_count[q] = 0; }
+        if (tid == 0) p.out_count[q] = 0;
         return;
     }
     const uint64_t* cand = p.cand + (uint64_t)q * p.cap;
