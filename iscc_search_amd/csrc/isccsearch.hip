@@ -153,11 +153,10 @@ struct isccsearch_handle {
     DevBuf<uint64_t> d_cand;
     DevBuf<isk::Record> d_lists, d_final;
     PinBuf<uint64_t> p_queries;     // pinned staging: queries in, flags / results out
-    PinBuf<uint32_t> p_flags, p_cnt;
+    PinBuf<uint32_t> p_flags;
     // one batch's results as ONE block {records [m][k] | counts [m] | overflow flags}: a single device->host copy
     DevBuf<unsigned char> d_block;
     PinBuf<unsigned char> p_block;
-    PinBuf<isk::Record> p_final;
     DevBuf<uint64_t> d_misc;        // moves / gather rows / single query
     DevBuf<uint64_t> d_misc2;
     std::vector<isk::Record> h_final;
@@ -756,7 +755,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         h->d_queries.release(); h->d_bias.release(); h->d_cnt.release(); h->d_ghist.release(); h->d_freq.release();
         h->d_overflow.release(); h->d_listcnt.release(); h->d_outcnt.release(); h->d_cand.release();
         h->d_lists.release(); h->d_final.release(); h->d_misc.release(); h->d_misc2.release();
-        h->p_queries.release(); h->p_flags.release(); h->p_cnt.release(); h->p_final.release();
+        h->p_queries.release(); h->p_flags.release();
         h->d_block.release(); h->p_block.release();
         if (h->d_rank) (void)hipFree(h->d_rank);
         for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
