@@ -153,6 +153,24 @@ int isccsearch_search_within(isccsearch_handle* h, uint32_t table, uint32_t nq, 
                              const uint8_t* q_nbytes, uint32_t k, uint32_t max_hamming,
                              uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
 
+/* Several searches in one call, one device synchronisation: what UsearchIndex.search_assets issues as a sequence of
+ * per-unit searches (similarity units iscc_search/indexes/usearch/index.py:786-806 -> :2037, INSTANCE unit :791-797
+ * -> :1957-2022) for ONE request.  Request i is isccsearch_search (max_hamming < 0) or isccsearch_search_within
+ * (max_hamming >= 0) on its own table with its own k and outputs; reqs[i].status receives its result code.  Returns 0
+ * or the first request's error code (the others still ran). */
+typedef struct isccsearch_request {
+    uint32_t table, nq, k;
+    int32_t max_hamming;
+    const uint64_t* q_words;      /* [nq*max_words] */
+    const uint8_t* q_nbytes;      /* [nq], NULL for Hamming tables */
+    uint64_t* out_keys;           /* [nq*k*key_words] */
+    uint32_t* out_hamming;        /* [nq*k] */
+    uint16_t* out_prefix_bits;    /* [nq*k] */
+    uint32_t* out_count;          /* [nq] */
+    int32_t status;               /* out */
+} isccsearch_request;
+int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request* reqs);
+
 /* Document frequency of nq codes: out_freq[q] = number of DISTINCT assets among the first dup_limit rows
  * (ascending key) that equal code q.  The asset is the first key word of a 2-word key (the ISCC-ID body of a
  * chunk pointer, lmdb_ops.py:30-49); with 1-word keys every row is its own asset.

@@ -25,7 +25,7 @@ EXPORTS = (
     "isccsearch_stats_get", "isccsearch_table_open", "isccsearch_table_drop", "isccsearch_reserve",
     "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
     "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
-    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_doc_freq", "isccsearch_get_freq",
+    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_search_many", "isccsearch_doc_freq", "isccsearch_get_freq",
     "isccsearch_search_device", "isccsearch_search_within_device", "isccsearch_merge_device",
 )
 
@@ -53,6 +53,25 @@ class Stats(ctypes.Structure):
     def as_dict(self):
         # type: () -> dict
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class Request(ctypes.Structure):
+    """``isccsearch_request``: one search of an ``isccsearch_search_many`` call."""
+
+    _fields_ = [
+        ("table", ctypes.c_uint32),
+        ("nq", ctypes.c_uint32),
+        ("k", ctypes.c_uint32),
+        ("max_hamming", ctypes.c_int32),
+        # pointers as plain addresses: filled from ndarray.ctypes.data (a typed POINTER cast costs ~2 us per field)
+        ("q_words", ctypes.c_void_p),
+        ("q_nbytes", ctypes.c_void_p),
+        ("out_keys", ctypes.c_void_p),
+        ("out_hamming", ctypes.c_void_p),
+        ("out_prefix_bits", ctypes.c_void_p),
+        ("out_count", ctypes.c_void_p),
+        ("status", ctypes.c_int32),
+    ]
 
 
 _LIB = None
@@ -106,6 +125,7 @@ def load_library():
         "isccsearch_add_synthetic": (i, [vp, u32, i, u64, u64, u64, u64]),
         "isccsearch_search": (i, [vp, u32, u32, u64p, u8p, u32, u64p, u32p, u16p, u32p]),
         "isccsearch_search_within": (i, [vp, u32, u32, u64p, u8p, u32, u32, u64p, u32p, u16p, u32p]),
+        "isccsearch_search_many": (i, [vp, u32, ctypes.POINTER(Request)]),
         "isccsearch_doc_freq": (i, [vp, u32, u32, u64p, u8p, u32, u32p]),
         "isccsearch_get_freq": (i, [vp, u32, u64, u64p, u32, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),

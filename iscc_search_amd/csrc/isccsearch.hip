@@ -372,6 +372,7 @@ struct Batch {
     uint32_t* d_out_cnt;      // [nq]     device
     int tq = 8;
     int radius = -1;          // >= 0: report only rows within this Hamming distance (fixed threshold, no sampling)
+    size_t pq_off = 0;                  // this batch's slice of the pinned query staging buffer (words)
     uint32_t* d_flags = nullptr;        // overflow flags [jobs][nq_pad]; the caller may place them inside its result block
     const uint32_t* h_flags = nullptr;  // where the host finds them after the copy (default: h->p_flags)
     uint32_t nq_pad = 0, groups = 0, cap = 0, P = 0;
@@ -444,11 +445,12 @@ struct Batch {
             if ((rc = h->d_listcnt.ensure(jobs.size() * (size_t)nq))) return rc;
         }
         // stage queries through pinned memory: [nq_pad][4], padded words zero
-        if ((rc = h->p_queries.ensure((size_t)nq_pad * 4))) return rc;
-        memset(h->p_queries.p, 0, (size_t)nq_pad * 4 * 8);
+        if ((rc = h->p_queries.ensure(pq_off + (size_t)nq_pad * 4))) return rc;   // (no-op when the caller pre-sized it)
+        uint64_t* const pq = h->p_queries.p + pq_off;
+        memset(pq, 0, (size_t)nq_pad * 4 * 8);
         for (uint32_t q = 0; q < nq; ++q)
-            for (int w = 0; w < t.max_words; ++w) h->p_queries.p[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
-        HIPOK(hipMemcpyAsync(h->d_queries.p, h->p_queries.p, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
+            for (int w = 0; w < t.max_words; ++w) pq[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
+        HIPOK(hipMemcpyAsync(h->d_queries.p, pq, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
 
         for (size_t ji = 0; ji < jobs.size(); ++ji) {
             const Job& j = jobs[ji];
@@ -1432,6 +1434,113 @@ int isccsearch_search(isccsearch_handle* h, uint32_t table, uint32_t nq, const u
     h->qcv.notify_all();
     if (me.rc) g_last_error = me.err;
     return me.rc;
+}
+
+// Several searches, ONE synchronisation.  Requests over single-segment tables whose queries share one length are
+// enqueued back to back (the device buffers are reused in stream order; only the pinned staging is sliced per
+// request) and their result blocks are read after a single hipStreamSynchronize; everything else -- and any
+// request whose candidate list overflowed -- takes the ordinary path afterwards.
+int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request* reqs) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    if (!reqs) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPOK(hipSetDevice(h->device));
+    struct Slot {
+        std::unique_ptr<Batch> batch;
+        std::vector<uint64_t> hq;
+        size_t block_off = 0, rec_bytes = 0;
+    };
+    std::vector<Slot> slots(n);
+    std::vector<bool> deferred(n, false);
+    int first_error = 0;
+    auto reject = [&](isccsearch_request& r, int rc) { r.status = rc; if (!first_error) first_error = rc; };
+
+    // pass 1: validate, pick the requests that can be deferred, size the pinned staging once (a later ensure()
+    // would move slices that are already referenced by queued copies)
+    size_t pq_words = 0, block_total = 0, block_max = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        isccsearch_request& r = reqs[i];
+        r.status = 0;
+        if (r.nq == 0) continue;
+        if (r.k < 1) { reject(r, fail(-EINVAL, "`count` must be >= 1")); continue; }
+        if (r.k > ISCCSEARCH_MAX_K) { reject(r, fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", r.k, ISCCSEARCH_MAX_K)); continue; }
+        if (r.max_hamming > 256) { reject(r, fail(-EINVAL, "max_hamming %d exceeds 256", r.max_hamming)); continue; }
+        if (!r.q_words || !r.out_keys || !r.out_hamming || !r.out_prefix_bits || !r.out_count) { reject(r, fail(-EINVAL, "NULL argument")); continue; }
+        Table* tp;
+        int rc = get_table(h, r.table, tp);
+        if (!rc) rc = check_query_lengths(*tp, r.nq, r.q_nbytes);
+        if (rc) { reject(r, rc); continue; }
+        const Table& t = *tp;
+        uint32_t segments = 0;
+        for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) segments += t.seg[b].n ? 1 : 0;
+        bool one_len = true;
+        if (t.metric == ISCCSEARCH_METRIC_NPHD)
+            for (uint32_t q = 1; q < r.nq; ++q) one_len = one_len && r.q_nbytes[q] == r.q_nbytes[0];
+        if (segments != 1 || !one_len || r.nq > QB_MAX) continue;     // ordinary path below
+        deferred[i] = true;
+        Slot& sl = slots[i];
+        sl.rec_bytes = (size_t)r.nq * r.k * sizeof(isk::Record);
+        const size_t bytes = (sl.rec_bytes + ((size_t)r.nq + (size_t)r.nq + 16) * sizeof(uint32_t) + 15) & ~(size_t)15;
+        sl.block_off = block_total;
+        block_total += bytes;
+        block_max = std::max(block_max, bytes);
+        pq_words += ((size_t)r.nq + 16) * 4;
+    }
+    int rc;
+    if ((rc = h->p_queries.ensure(pq_words))) return rc;
+    if ((rc = h->p_block.ensure(block_total))) return rc;
+    if ((rc = h->d_block.ensure(block_max))) return rc;
+
+    // pass 2: enqueue
+    size_t pq_off = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!deferred[i]) continue;
+        isccsearch_request& r = reqs[i];
+        Table& t = *h->tables[r.table];
+        Slot& sl = slots[i];
+        const uint32_t len = t.metric == ISCCSEARCH_METRIC_NPHD ? r.q_nbytes[0] : (uint32_t)t.max_bytes;
+        isk::Record* const d_rec = reinterpret_cast<isk::Record*>(h->d_block.p);
+        uint32_t* const d_cnt = reinterpret_cast<uint32_t*>(h->d_block.p + sl.rec_bytes);
+        uint32_t* const p_cnt = reinterpret_cast<uint32_t*>(h->p_block.p + sl.block_off + sl.rec_bytes);
+        sl.batch.reset(new Batch(h, t, r.nq, len, r.k, d_rec, d_cnt));
+        Batch& b = *sl.batch;
+        b.radius = r.max_hamming < 0 ? -1 : r.max_hamming;
+        b.pq_off = pq_off;
+        b.d_flags = d_cnt + r.nq;
+        b.h_flags = p_cnt + r.nq;
+        pq_off += ((size_t)r.nq + 16) * 4;
+        sl.hq.assign(r.q_words, r.q_words + (size_t)r.nq * t.max_words);
+        h->stats.searches += 1;
+        h->stats.queries += r.nq;
+        if ((rc = b.begin(sl.hq.data()))) return rc;
+        const size_t bytes = sl.rec_bytes + ((size_t)r.nq + b.flag_words()) * sizeof(uint32_t);
+        HIPOK(hipMemcpyAsync(h->p_block.p + sl.block_off, h->d_block.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPOK(hipStreamSynchronize(h->stream));
+
+    // pass 3: hand out the results; overflowed and non-deferred requests run the ordinary pipeline
+    for (uint32_t i = 0; i < n; ++i) {
+        isccsearch_request& r = reqs[i];
+        if (r.status || r.nq == 0) continue;
+        bool ordinary = !deferred[i];
+        if (deferred[i]) {
+            Batch& b = *slots[i].batch;
+            if (!b.jobs.empty() && b.any_flag()) ordinary = true;     // rare: exact fallback through the normal path
+            else {
+                const isk::Record* p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p + slots[i].block_off);
+                const uint32_t* p_cnt = reinterpret_cast<const uint32_t*>(h->p_block.p + slots[i].block_off + slots[i].rec_bytes);
+                unpack_records(p_rec, p_cnt, r.nq, r.k, h->tables[r.table]->key_words, nullptr, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count);
+            }
+        }
+        if (ordinary) {
+            if (!deferred[i]) h->stats.searches += 1;
+            rc = search_locked(h, r.table, r.nq, r.q_words, r.q_nbytes, r.k, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count,
+                               r.max_hamming < 0 ? -1 : r.max_hamming);
+            if (rc) reject(r, rc);
+        }
+    }
+    return first_error;
 }
 
 int isccsearch_search_within(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,

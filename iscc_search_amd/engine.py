@@ -100,6 +100,39 @@ class HipEngine:
         )
         return out
 
+    def search_many(self, requests):
+        # type: (list[tuple]) -> list[tuple]
+        """
+        Several searches with ONE device synchronisation (``isccsearch_search_many``): the per-unit searches of
+        one ``search_assets`` request (``usearch/index.py:786-806``).  ``requests`` = [(table, q_words, q_nbytes, k,
+        max_hamming or None)]; returns [(keys, hamming, prefix_bits, count)] shaped as ``HipTable.search``.
+        """
+        n = len(requests)
+        if n == 0:
+            return []
+        arr = (_lib.Request * n)()
+        keep, outs = [], []
+        for i, (table, q_words, q_nbytes, k, max_hamming) in enumerate(requests):
+            if k < 1:
+                raise ValueError("`count` must be >= 1")
+            q_words = table._words(q_words)
+            nq = q_words.shape[0]
+            q_nbytes = table._nbytes(q_nbytes, nq)
+            out = _alloc_out(nq, k, table.key_words)
+            keep.append((q_words, q_nbytes))
+            outs.append(out)
+            r = arr[i]
+            r.table, r.nq, r.k = table.id, nq, k
+            r.max_hamming = -1 if max_hamming is None else int(max_hamming)
+            r.q_words = q_words.ctypes.data
+            r.q_nbytes = q_nbytes.ctypes.data if q_nbytes is not None else None
+            r.out_keys = out[0].ctypes.data
+            r.out_hamming = out[1].ctypes.data
+            r.out_prefix_bits = out[2].ctypes.data
+            r.out_count = out[3].ctypes.data
+        _lib.check(self._lib.isccsearch_search_many(self.handle, n, arr))
+        return outs
+
     def close(self):
         # type: () -> None
         """Idempotent (``protocols/index.py:167-172``)."""

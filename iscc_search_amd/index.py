@@ -25,6 +25,7 @@ import numpy as np
 
 from iscc_search_amd import codec
 from iscc_search_amd._lib import MAX_K
+from iscc_search_amd.engine import pack_bytes
 from iscc_search_amd.nphd import HipNphdIndex
 from iscc_search_amd.schema import (
     IsccAddResult, IsccChunkMatch, IsccEntry, IsccGlobalMatch, IsccIndex, IsccMatchedChunk, IsccQuery,
@@ -244,6 +245,39 @@ class HipIndex:
         m = table.search_within(np.frombuffer(body, dtype=np.uint8), count=MAX_K, max_hamming=0)
         return {int(key): 1.0 for key in m.keys}
 
+    def _search_units(self, units, limit):
+        # type: (List[str], int) -> Dict[int, Dict[str, float]]
+        """
+        The per-unit searches of one request (``usearch/index.py:786-806``: one ``search`` per similarity unit, one
+        prefix match per INSTANCE unit) as ONE engine call with one device synchronisation; merged exactly as
+        the reference merges its per-unit dicts (max per (key, unit_type), :806; INSTANCE hits score 1.0, :2010).
+        """
+        plan, requests = [], []
+        for unit_str in units:
+            unit = codec.Iscc(unit_str)
+            index = self._unit_tables.get(unit.unit_type)
+            if index is None:
+                continue
+            words, nbytes = pack_bytes([unit.body], index._table.max_words)
+            if unit.unit_type.startswith("INSTANCE_"):
+                requests.append((index._table, words, nbytes, MAX_K, 0))
+            else:
+                requests.append((index._table, words, nbytes, min(limit, MAX_K), None))
+            plan.append(unit.unit_type)
+        aggregated = {}  # type: Dict[int, Dict[str, float]]
+        for unit_type, (keys, ham, pbits, cnt) in zip(plan, self._engine.search_many(requests)):
+            c = int(cnt[0])
+            if unit_type.startswith("INSTANCE_"):
+                for key in keys[0, :c]:
+                    aggregated.setdefault(int(key), {})[unit_type] = 1.0
+                continue
+            # float32 NPHD as HipNphdIndex.search hands it out, then the reference's float64 `1.0 - d` clamp (:2041-2043)
+            dist = ham[0, :c].astype(np.float32) / pbits[0, :c].astype(np.float32)
+            for key, d in zip(keys[0, :c], dist):
+                slot = aggregated.setdefault(int(key), {})
+                slot[unit_type] = max(slot.get(unit_type, 0.0), max(0.0, 1.0 - float(d)))
+        return aggregated
+
     def search_assets(self, query, limit=100, exact=False):
         # type: (IsccQuery, int, bool) -> IsccSearchResult
         """``exact=True`` matches simprints by collision only (``usearch/index.py:735-778, :1261-1304``)."""
@@ -261,17 +295,7 @@ class HipIndex:
             chunk_matches = self._search_simprints(query, limit, exact=exact)
         matches = []
         if query.units:
-            aggregated = {}  # type: Dict[int, Dict[str, float]]
-            for unit_str in query.units:
-                unit = codec.Iscc(unit_str)
-                unit_type = unit.unit_type
-                if unit_type.startswith("INSTANCE_"):
-                    for key, score in self._search_instance_unit(unit_type, unit.body).items():
-                        aggregated.setdefault(key, {})[unit_type] = score
-                elif unit_type in self._unit_tables:
-                    for key, score in self._search_similarity_unit(unit_type, unit.body, limit).items():
-                        slot = aggregated.setdefault(key, {})
-                        slot[unit_type] = max(slot.get(unit_type, 0.0), score)
+            aggregated = self._search_units(query.units, limit)
             scored = []
             thr, exp = self._opts.match_threshold_units, self._opts.confidence_exponent
             for key, unit_scores in aggregated.items():

@@ -205,5 +205,12 @@ class OracleEngine:
         t.engine = self
         return t
 
+    def search_many(self, requests):
+        out = []
+        for table, q_words, q_nbytes, k, max_hamming in requests:
+            q_words = np.asarray(q_words, dtype=np.uint64).reshape(-1, table.max_words)
+            out.append(table.search(q_words, q_nbytes, k) if max_hamming is None else table.search_within(q_words, q_nbytes, k, max_hamming))
+        return out
+
     def close(self):
         pass
