@@ -111,7 +111,15 @@ def test_random_operation_sequences(hip_engine, seed):
                 q[:, 0] ^= rng.integers(0, 16, size=nq).astype(np.uint64)
                 q = _mask(q, qlens if metric == 1 else max_bytes)
                 assert t.size == model.size
-                _compare(t.search(q, qlens, k), model.search(q, qlens, k), f"seed={seed} step={step} tq={tq} nq={nq} k={k}")
+                tag = f"seed={seed} step={step} tq={tq} nq={nq} k={k}"
+                if rng.random() < 0.4:
+                    # the same search as one of several requests of a search_many call (deferred or ordinary path)
+                    k2, r2 = int(rng.choice([1, 10, 300])), int(rng.choice([0, 2]))
+                    many = hip_engine.search_many([(t, q[:7], None if qlens is None else qlens[:7], k2, r2), (t, q, qlens, k, None)])
+                    _compare(many[1], model.search(q, qlens, k), "many " + tag)
+                    _compare(many[0], model.search_within(q[:7], None if qlens is None else qlens[:7], k2, r2), "many/within " + tag)
+                else:
+                    _compare(t.search(q, qlens, k), model.search(q, qlens, k), tag)
         assert t.size == model.size
     finally:
         t.drop()
