@@ -89,6 +89,7 @@ struct Scratch {
 };
 
 int failed(std::string* err, int code, const char* what, hipError_t e) {
+    (void)hipGetLastError();   // do not leave the code behind for an unrelated later launch check
     if (err) {
         char buf[256];
         snprintf(buf, sizeof buf, "document-frequency column: %s: %s", what, hipGetErrorString(e));

@@ -44,12 +44,16 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// A failed HIP call also leaves its code in the runtime's "last error" slot, where the next
+// hipGetLastError() -- the launch check of an unrelated, later call -- would find it: clear it when reporting.
 #define HIPOK(expr)                                                                              \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
+        if (e_ != hipSuccess) {                                                                  \
+            (void)hipGetLastError();                                                             \
             return fail(e_ == hipErrorOutOfMemory ? -ENOMEM : -EIO, "%s failed: %s (%s:%d)", #expr, \
                         hipGetErrorString(e_), __FILE__, __LINE__);                              \
+        }                                                                                        \
     } while (0)
 
 using iskhost::Key;
@@ -93,7 +97,7 @@ struct DevBuf {
         n = 0;
         size_t want = need + need / 4;
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; return fail(-ENOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(-ENOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
         n = want;
         return 0;
     }
@@ -111,7 +115,7 @@ struct PinBuf {   // page-locked host memory: async copies really are asynchrono
         n = 0;
         size_t want = need + need / 4 + 16;
         hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
-        if (e != hipSuccess) { p = nullptr; return fail(-ENOMEM, "hipHostMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(-ENOMEM, "hipHostMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
         n = want;
         return 0;
     }
@@ -197,11 +201,11 @@ int seg_reserve(H* h, Table& t, Segment& s, uint64_t need) {
     auto cleanup = [&]() { for (auto& c : ncol) if (c) (void)hipFree(c); if (nkeys) (void)hipFree(nkeys); };
     for (uint32_t w = 0; w < s.W; ++w) {
         hipError_t e = hipMalloc((void**)&ncol[w], cap * 8);
-        if (e != hipSuccess) { cleanup(); return fail(-ENOMEM, "hipMalloc(column, %llu bytes) failed: %s", (unsigned long long)cap * 8, hipGetErrorString(e)); }
+        if (e != hipSuccess) { cleanup(); (void)hipGetLastError(); return fail(-ENOMEM, "hipMalloc(column, %llu bytes) failed: %s", (unsigned long long)cap * 8, hipGetErrorString(e)); }
     }
     {
         hipError_t e = hipMalloc((void**)&nkeys, cap * 8 * t.key_words);
-        if (e != hipSuccess) { cleanup(); return fail(-ENOMEM, "hipMalloc(keys) failed: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { cleanup(); (void)hipGetLastError(); return fail(-ENOMEM, "hipMalloc(keys) failed: %s", hipGetErrorString(e)); }
     }
     if (s.n) {
         for (uint32_t w = 0; w < s.W; ++w) HIPOK(hipMemcpyAsync(ncol[w], s.col[w], s.n * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -1198,7 +1202,7 @@ int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const 
             if (s.freq) { (void)hipFree(s.freq); s.freq = nullptr; }
             s.freq_rows = 0;
             hipError_t e = hipMalloc((void**)&s.freq, s.n * sizeof(uint32_t));
-            if (e != hipSuccess) { s.freq = nullptr; return fail(-ENOMEM, "hipMalloc(frequency column, %llu bytes) failed: %s", (unsigned long long)s.n * 4, hipGetErrorString(e)); }
+            if (e != hipSuccess) { s.freq = nullptr; (void)hipGetLastError(); return fail(-ENOMEM, "hipMalloc(frequency column, %llu bytes) failed: %s", (unsigned long long)s.n * 4, hipGetErrorString(e)); }
             std::string err;
             if ((rc = iskdf::build_freq_column(s.col, (int)s.W, s.keys, KW, s.n, dup_limit, s.freq, h->stream, &err))) return fail(rc, "%s", err.c_str());
             s.freq_rows = s.n;

@@ -230,3 +230,19 @@ def test_two_shards_within_merged_on_device_equal_the_unsharded_answer(hip_engin
     finally:
         for t in shards + [whole]:
             t.drop()
+
+
+def test_out_of_memory_is_reported_and_the_engine_stays_usable(hip_engine):
+    """A reservation beyond the 288 GB of HBM fails with -ENOMEM -> MemoryError; tables and searches keep working."""
+    t = hip_engine.open_table(METRIC_HAMMING, 1, 8)
+    try:
+        t.add(np.array([1, 2, 3], dtype=np.uint64), np.array([[5], [6], [7]], dtype=np.uint64))
+        with pytest.raises(MemoryError):
+            t.reserve(8, 60_000_000_000)          # 60 G rows x (8 B code + 8 B key) = 960 GB
+        assert t.size == 3
+        keys, ham, _, cnt = t.search(np.array([[5]], dtype=np.uint64), None, 2)
+        assert cnt.tolist() == [2] and keys[0].tolist() == [1, 3] and ham[0].tolist() == [0, 1]
+        t.add(np.array([4], dtype=np.uint64), np.array([[5]], dtype=np.uint64))
+        assert t.search_within(np.array([[5]], dtype=np.uint64), None, 10, 0)[3].tolist() == [2]
+    finally:
+        t.drop()
