@@ -8,8 +8,11 @@
 //   per overflowed query (rare):  fullhist -> exact threshold -> scan(COLLECT) into a sized
 //                                 buffer -> select
 //
+//   range-limited (search_within / doc_freq): radius_init -> scan(COLLECT) -> select   (fixed threshold)
+//
 // Everything runs on one HIP stream owned by the handle; the only host synchronisation of a
-// search is the final result copy.  Built for gfx950 only (hipcc --offload-arch=gfx950).
+// search is the final result copy (one block {records | counts | flags}); search_many shares it between
+// the requests of one call.  Built for gfx950 only (hipcc --offload-arch=gfx950).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -21,7 +21,11 @@
 //                  sort of the k winners in LDS, emit records
 //   fullhist_kernel exact histogram of one query over a whole segment (overflow fallback)
 //   merge_kernel   k-way merge of sorted record lists (segments of a table, shards of a node)
-//   plus small utilities (synthetic fill, row moves, row gathers)
+//   radius_init_kernel  range-limited searches: the given threshold for every query (no bootstrap, no samples)
+//   distinct_kernel     document frequency: distinct assets in a key-ordered collision list
+//   plus small utilities (synthetic fill, row moves, row / frequency gathers); the sort-based frequency
+//   column lives in docfreq.hip
+//   Wide query groups (TQ*W >= 24) hold their queries in LDS instead of SGPRs (queries_in_lds).
 //
 // No MFMA: this is integer bit work bound by HBM reads (roofline in DESIGN.md section 4).
 #pragma once
