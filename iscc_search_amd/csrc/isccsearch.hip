@@ -907,6 +907,17 @@ int isccsearch_add(isccsearch_handle* h, uint32_t table, uint64_t n, const uint6
         const uint64_t* kp = keys;
         if (direct) {
             HIPOK(hipMemcpyAsync(s.col[0] + s.n, code_words, m * 8, hipMemcpyHostToDevice, h->stream));
+        } else if (m == n) {
+            // one code length, several words: ship the caller's row-major block as it is and split it into the
+            // word columns on the device (a host-side transposition capped 256-bit ingest at 80 M rows/s)
+            if ((rc = h->d_misc2.ensure((size_t)n * MW))) return rc;
+            HIPOK(hipMemcpyAsync(h->d_misc2.p, code_words, (size_t)n * MW * 8, hipMemcpyHostToDevice, h->stream));
+            isk::SplitParams sp{};
+            for (uint32_t w = 0; w < s.W; ++w) sp.col[w] = s.col[w];
+            sp.rows = h->d_misc2.p; sp.dst_row = s.n; sp.n = n; sp.W = s.W; sp.MW = (uint32_t)MW; sp.mask_last = mask_for(b);
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((n + isk::BLOCK - 1) / isk::BLOCK, (uint64_t)h->cus * 8);
+            hipLaunchKernelGGL(isk::split_rows_kernel, dim3(grid), dim3(isk::BLOCK), 0, h->stream, sp);
+            HIPOK(hipGetLastError());
         } else {
             stage.resize((size_t)m * s.W);
             uint64_t j = 0;

@@ -1003,6 +1003,23 @@ __global__ __launch_bounds__(BLOCK) void gather_rows_kernel(const GatherParams p
         for (uint32_t w = 0; w < p.W; ++w) p.out[i * p.W + w] = p.col[w][p.rows[i]];
 }
 
+// ingest: rows handed over row-major [n][MW] -> the segment's word columns (the last kept word masked to the code length)
+struct SplitParams {
+    uint64_t* col[4];
+    const uint64_t* rows;    // [n][MW]
+    uint64_t dst_row, n;
+    uint32_t W, MW;
+    uint64_t mask_last;
+};
+__global__ __launch_bounds__(BLOCK) void split_rows_kernel(const SplitParams p) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < p.n; i += (uint64_t)gridDim.x * BLOCK)
+        for (uint32_t w = 0; w < p.W; ++w) {
+            uint64_t v = p.rows[i * p.MW + w];
+            if (w == p.W - 1) v &= p.mask_last;
+            p.col[w][p.dst_row + i] = v;
+        }
+}
+
 // out[i] = src[rows[i]]  (document-frequency column lookups)
 __global__ __launch_bounds__(BLOCK) void gather_u32_kernel(const uint32_t* src, const uint64_t* rows, uint32_t* out, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) out[i] = src[rows[i]];
