@@ -433,7 +433,7 @@ struct Batch {
             HIPOK(hipMemsetAsync(d_out_cnt, 0, nq * sizeof(uint32_t), h->stream));
             return 0;
         }
-        cap = std::max<uint32_t>(16384, 8 * k);
+        cap = std::max<uint32_t>(16384, 16 * k);
         multi = jobs.size() > 1;
         P = next_pow2(std::max<uint32_t>(k, 1024));   // select's LDS sort buffer: room for small tie classes (12-20 KB)
         sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
@@ -490,35 +490,40 @@ struct Batch {
             bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.cnt = h->d_cnt.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
             hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
 
-            // 2. sample scans: tighten the threshold level by level.  A scan of S rows under the threshold
-            //    of a sample of S' rows meets ~4096*k/S' candidates per wave-tile (each costs a fraction of
-            //    a tile), so every level grows the sample (8x; 64x when there are so few query groups
-            //    that launch gaps outweigh candidate handling), and the last level stops where its own
-            //    cost balances the candidate handling it saves the full scan:
-            //    S_last ~ sqrt(cost * 4096 * k * n).
-            const double balance = std::sqrt((double)h->sample_cost / 100.0 * 4096.0 * (double)k * (double)s.n);
+            // 2. levels: every level streams the NEXT stretch of rows [done, end) exactly once under the threshold of the
+            //    rows before it, collecting its candidates and adding them to the running histogram (MODE_BOTH);
+            //    pick_kernel then tightens the threshold to the k-th best so far and prunes the candidate list to
+            //    it.  A level meets ~k * growth candidates per query, so the stretches grow geometrically (8x;
+            //    64x when there are so few query groups that launch gaps outweigh candidate handling; less
+            //    when k * growth would not fit the candidate buffer).  No row is read twice.
             const uint64_t tile_rows = (uint64_t)tile_rows_for((int)j.W);
-            uint64_t s_last = std::min<uint64_t>(s.n, std::max<uint64_t>(s0, (uint64_t)balance));
-            // the LAST level also collects (MODE_BOTH), so the streaming pass starts where it ended: keep that
-            // boundary on a tile edge; a sample that covers the whole segment leaves nothing to stream
-            if (s_last < s.n) s_last = s_last / tile_rows * tile_rows;
-            if (s_last + tile_rows > s.n) s_last = s.n;
-            const uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;      // (boot_kernel zeroed the candidate counters)
-            uint64_t collected_to = 0;            // rows [0, collected_to) already have their candidates appended
-            bool hist_live = false;               // d_ghist holds the histogram of exactly those rows
-            sp.row_begin = 0;
-            for (uint64_t sample = s0; sample < s_last;) {
-                sample = std::min<uint64_t>(s_last, sample * growth);
-                const bool last = sample == s_last;
-                HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
-                sp.n_rows = sample;
-                launch_scan((int)j.W, j.mask, tq, last ? isk::MODE_BOTH : isk::MODE_HIST, h->nontemporal,
-                            dim3(scan_grid_x(h, j.W, sample, groups, true), groups), h->stream, sp);
-                isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, sample)};
+            uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;
+            // a stretch `growth` times the rows seen so far brings ~growth * (rows at or under tau) candidates, and the
+            // tie class at tau can make that 2.3x k (ratio of consecutive binomial tails): keep it inside the buffer
+            while (growth > 2 && (uint64_t)k * growth * 5 / 2 > (uint64_t)cap * 9 / 10) growth /= 2;
+            uint64_t done = 0;                    // rows [0, done) are collected and in the histogram
+            bool hist_live = false;
+            uint64_t reach = s0;                  // the threshold in force comes from rows [0, reach)
+            for (;;) {
+                uint64_t end = reach >= s.n / growth ? s.n : reach * growth;
+                if (end < s.n) end = end / tile_rows * tile_rows;
+                if (end <= done || end + tile_rows > s.n) end = s.n;
+                const bool last = end == s.n;
+                if (last) break;                  // the final stretch is the streaming pass below
+                if (!hist_live) {
+                    HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
+                    hist_live = true;
+                }
+                sp.row_begin = done;
+                sp.n_rows = end;
+                launch_scan((int)j.W, j.mask, tq, isk::MODE_BOTH, h->nontemporal,
+                            dim3(scan_grid_x(h, j.W, end - done, groups, true), groups), h->stream, sp);
+                isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, end), h->d_cnt.p, h->d_cand.p, cap};
                 hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
-                h->stats.sample_bytes += sample * 8 * j.W * groups;
-                if (last) { collected_to = sample; hist_live = true; }
+                h->stats.sample_bytes += (end - done) * 8 * j.W * groups;
+                done = reach = end;
             }
+            const uint64_t collected_to = done;
 
             // 3. the streaming pass: collect every remaining row within the threshold
             if (collected_to < s.n) {

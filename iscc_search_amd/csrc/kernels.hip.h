@@ -572,22 +572,55 @@ struct PickParams {
     const uint32_t* ghist;   // [nq_pad][HB]
     uint32_t* bias;          // [nq_pad] in/out
     uint32_t nq;
-    uint32_t need;           // min(k, sample rows)
+    uint32_t need;           // min(k, rows seen so far)
+    uint32_t* cnt;           // [nq_pad * CNT_STRIDE] candidate counters   (nullptr: no pruning)
+    uint64_t* cand;          // [nq_pad][cap] candidate lists, pruned in place to the new threshold
+    uint32_t cap;
 };
 
-// one block per query: tau1 = first bin of the sample histogram where the running count >= need
+// one block per query: tau = first bin of the running histogram where the count reaches `need`; then the
+// candidates collected so far under looser thresholds are pruned to it, so that the list holds ~need entries
+// (+ ties) whatever the number of levels.
 __global__ __launch_bounds__(BLOCK) void pick_kernel(const PickParams p) {
     __shared__ uint32_t hist[320];
     __shared__ uint32_t res[2];
+    __shared__ uint32_t wsum[BLOCK / 64];
+    __shared__ uint32_t base;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     if (q >= p.nq) return;
     for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = i < NBINS ? p.ghist[(uint64_t)q * HB + i] : 0u;
     __syncthreads();
     uint32_t bin, less;
     block_find_cut(hist, NBINS, p.need, res, bin, less);
-    // never loosen the bootstrap threshold (the sample histogram only holds bins <= tau0)
+    // never loosen the threshold (the histogram only holds bins <= the threshold its rows were scanned under)
     const uint32_t tau0 = 0x7FFFFFFFu - p.bias[q];
-    if (tid == 0) p.bias[q] = 0x7FFFFFFFu - (bin < tau0 ? bin : tau0);
+    const uint32_t tau = bin < tau0 ? bin : tau0;
+    if (tid == 0) { p.bias[q] = 0x7FFFFFFFu - tau; base = 0; }
+    if (!p.cand) return;
+    const uint32_t total = p.cnt[(uint64_t)q * CNT_STRIDE];
+    if (total > p.cap) return;            // overflowed: select_kernel flags it, the host reruns the query exactly
+    uint64_t* list = p.cand + (uint64_t)q * p.cap;
+    __syncthreads();
+    // in-place stable compaction, one 256-entry chunk at a time: a chunk is read into registers before anything
+    // of it is written, and the write position never passes the read position
+    for (uint32_t start = 0; start < total; start += BLOCK) {
+        const uint32_t i = start + tid;
+        uint64_t c = 0;
+        bool keep = false;
+        if (i < total) { c = list[i]; keep = (uint32_t)(c >> 48) <= tau; }
+        const uint64_t ball = __ballot(keep);
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        const uint32_t before = (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(ball);
+        __syncthreads();
+        uint32_t off = base;
+        for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+        __syncthreads();
+        if (keep) list[off + before] = c;
+        if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) p.cnt[(uint64_t)q * CNT_STRIDE] = base;
 }
 
 // ---------------------------------------------------------------------------------------------
