@@ -34,6 +34,7 @@ SEED_CODES = 0x1511CC00
 SEED_Q = 0x1511CC02
 SEED_P = 0x1511CC03
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
+VALU_PEAK_TLANEOPS = 39.3  # 1024 SIMDs x 16 lanes x 2.4 GHz (profiles/r01_micro_valu.txt: 4 cycles per wave64 integer op)
 MASK64 = (1 << 64) - 1
 
 
@@ -76,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
+    ap.add_argument("--no-streaming-check", action="store_true", help="skip the extra HBM-streaming measurement (stretch_mb=0) after the timed region")
     ap.add_argument("--force-collective", action="store_true", help="initialise RCCL and run the all-gather even with one rank (rehearsal)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     args = ap.parse_args()
@@ -116,6 +118,10 @@ def main():
     for kv in args.opt:
         name, _, val = kv.partition("=")
         engine.set_option(name, int(val))
+    stretch_mb = 128
+    for kv in args.opt:
+        if kv.startswith("stretch_mb="):
+            stretch_mb = int(kv.split("=")[1])
     nphd = args.metric == "nphd"
     table = engine.open_table(_lib.METRIC_NPHD if nphd else _lib.METRIC_HAMMING, 1, args.nbytes)
     q_nbytes = np.full(args.queries, args.nbytes, dtype=np.uint8) if nphd else None
@@ -162,15 +168,58 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # Outside the timed region, rank 0 of a one-GPU run: the same steps with cache blocking OFF, i.e. every query
+    # group streams the table from HBM -- the measurement that evidences the HBM roofline of the scan kernel
+    # (with blocking on, all but the first group of a launch read their stretch from the 256 MB Infinity Cache).
+    streaming = None
+    if world == 1 and not args.no_profile and not args.no_streaming_check:
+        engine.set_option("stretch_mb", 0)
+        step()
+        torch.cuda.synchronize()
+        engine.stats(reset=True)
+        engine.set_option("profile", 1)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        engine.set_option("profile", 0)
+        s2 = engine.stats(reset=True)
+        if s2["scan_ms"] > 0:
+            a2 = (s2["scan_bytes"] / 1e9) / (s2["scan_ms"] / 1e3)
+            streaming = {
+                "what": "same workload with stretch_mb=0 (no cache blocking): every pass streams the rows from HBM",
+                "bound": "hbm", "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,
+                "launches": s2["scan_launches"], "avg_launch_ms": s2["scan_ms"] / s2["scan_launches"],
+                "algorithmic_bytes_per_launch": s2["scan_bytes"] / s2["scan_launches"],
+                "queries_per_s": args.queries * 5 / el,
+            }
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size_scan_tq8.json")) as f:
+                    per_row = json.load(f)["corrected_bytes_per_row_pass_streaming"]
+                if args.nbytes == 8 and args.tq == 8:
+                    streaming["traffic"] = per_row * streaming["algorithmic_bytes_per_launch"] / 8.0
+            except (OSError, KeyError, ValueError):
+                pass
+
     # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected x2
     # for gfx950's half-count of 16 B/lane streams): bytes per pass for this workload, scaled to one launch.
     traffic = None
+    traffic_src = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size_scan_tq8.json")) as f:
             pmc = json.load(f)
-        if args.rows == 100_000_000 and args.nbytes == 8 and world == 1 and st["scan_launches"]:
-            # per-pass HBM bytes of the streaming scan for this exact workload (rows, k fix what the pass covers)
-            traffic = pmc["corrected_bytes_per_pass"] * st["scan_passes"] / st["scan_launches"]
+        per_row = None
+        if args.nbytes == 8 and args.tq == 8 and world == 1:
+            if stretch_mb == 0 or args.queries <= args.tq:
+                per_row = pmc["corrected_bytes_per_row_pass_streaming"]
+            elif stretch_mb == 128 and args.queries == 1024:
+                per_row = pmc["corrected_bytes_per_row_pass"]
+        if per_row and st["scan_launches"]:
+            # bytes the L2s fetched per (row, query group) of the collect scan, scaled to one launch of this run
+            traffic = per_row * (st["scan_bytes"] / 8.0) / st["scan_launches"]
+            traffic_src = ("profiles/r01_pmc_fetch_size_scan_tq8.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; "
+                           "FETCH_SIZE counts L2 misses, Infinity-Cache hits included)")
     except (OSError, KeyError, ValueError):
         traffic = None
 
@@ -209,10 +258,14 @@ def main():
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
             "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_fetch_size_scan_tq8.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)" if traffic else None,
+            "traffic_source": traffic_src,
             "launches": st["scan_launches"],
             "avg_launch_ms": (st["scan_ms"] / st["scan_launches"]) if st["scan_launches"] else None,
             "algorithmic_bytes_per_launch": (st["scan_bytes"] / st["scan_launches"]) if st["scan_launches"] else None,
+            "regime": ("cache-blocked: %d query groups per launch share stretches of <= %d MB, read from HBM once and from the "
+                       "256 MB Infinity Cache afterwards, so the algorithmic rate may exceed what HBM alone delivers; the kernel "
+                       "is then bound by integer VALU issue (see `valu`); `roofline_streaming` is the HBM-bound measurement"
+                       % (st["scan_passes"] // max(1, st["scan_launches"]), stretch_mb)) if stretch_mb and args.queries > args.tq else "streaming",
             "measured_copy_ceiling_GBs": 6290.0,          # MI355X_MICROARCH.md: measured streaming copy
             "measured_read_ceiling_GBs": 7050.0,          # profiles/r01_micro_read.txt: pure nontemporal read, same device
         },
@@ -221,6 +274,13 @@ def main():
         "whole_step_GBs": ((st["scan_bytes"] + st["sample_bytes"]) / 1e9) / elapsed,
         "fallback_queries": st["fallback_queries"],
     }
+    if achieved:
+        # 4.5 VALU lane-operations per (row, query, 64-bit word): the other roofline of this kernel
+        lane_ops = achieved * 1e9 / 8.0 * args.tq * 4.5
+        out["roofline"]["valu"] = {"achieved": lane_ops / 1e12, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                                   "frac": lane_ops / 1e12 / VALU_PEAK_TLANEOPS}
+    if streaming:
+        out["roofline_streaming"] = streaming
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, q, words)

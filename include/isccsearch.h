@@ -81,7 +81,7 @@ typedef struct isccsearch_stats {
     uint64_t scan_passes;     /* query groups streamed over a segment by those launches       */
     uint64_t scan_bytes;      /* ALGORITHMIC bytes of those passes: rows * 8 * words compared */
     double   scan_ms;         /* summed device time of those launches (only while profiling)  */
-    uint64_t sample_bytes;    /* bytes streamed by the threshold (sample) scans               */
+    uint64_t sample_bytes;    /* ALGORITHMIC bytes of the threshold levels (first stretch, read once) */
     uint64_t fallback_queries;/* queries that took the exact full-histogram fallback          */
     uint32_t queries_per_pass;/* T_q: queries held in SGPRs per streaming pass                */
     uint32_t compute_units;   /* CUs of the device                                            */
@@ -94,7 +94,9 @@ int isccsearch_destroy(isccsearch_handle* h);
 const char* isccsearch_last_error(void);
 
 /* Options: "queries_per_pass" (8|10|12|16), "profile" (0|1: time every collect-scan launch with HIP
- * events, read back through isccsearch_stats_get); tuning: "blocks_per_cu", "boot_rows", "sample_cost". */
+ * events, read back through isccsearch_stats_get), "stretch_mb" (rows per collect launch, in MB of codes, when
+ * several query groups share a launch: they then read the stretch from the caches instead of HBM; default 128,
+ * 0 = one streaming pass per group); tuning: "blocks_per_cu", "boot_rows", "level_growth". */
 int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);
 int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset);
 

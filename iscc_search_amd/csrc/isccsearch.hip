@@ -87,6 +87,7 @@ struct Table {
 };
 
 constexpr uint32_t QB_MAX = 1024;        // queries per pipeline run
+constexpr uint64_t CACHE_STRETCH_BYTES = 128ull << 20;   // half of the 256 MiB Infinity Cache
 constexpr uint64_t ROW_ALIGN = 2048;     // column capacities are multiples of the largest tile
 
 template <typename T>
@@ -151,7 +152,8 @@ struct isccsearch_handle {
     bool nontemporal = true;
     uint32_t blocks_per_cu = 8;    // scan grid = CUs x this (per query group)
     uint64_t boot_rows = 4096;     // rows of the threshold bootstrap (exact histogram per query)
-    uint64_t sample_cost = 100;    // relative cost (percent of a tile) of one candidate in a scan; sizes the last sample
+    uint64_t level_growth = 8;     // each threshold level streams this many times the rows seen so far
+    uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
     // scratch
@@ -465,19 +467,44 @@ struct Batch {
             Ctx c = make_ctx(ji);
             isk::ScanParams& sp = c.sp;
 
+            // the collect pass over rows [from, n) within the thresholds in force.  With more than one query group the
+            // rows are taken in STRETCHES that fit the Infinity Cache (option "stretch_mb", default 128 of its
+            // 256 MB): all groups of a launch walk the same stretch, so it comes out of HBM once and out of the
+            // caches for every further group -- the pass is then bound by the VALU, not by HBM.
+            const uint64_t tile_rows = (uint64_t)tile_rows_for((int)j.W);
+            bool hist_live = false;
+            auto collect_from = [&](uint64_t from) -> int {
+                uint64_t stretch = s.n;
+                if (groups > 1 && h->stretch_bytes) stretch = std::max<uint64_t>(tile_rows, h->stretch_bytes / (8 * j.W) / tile_rows * tile_rows);
+                for (uint64_t a = from; a < s.n;) {
+                    const uint64_t b = s.n - a <= stretch + stretch / 4 ? s.n : a + stretch;     // no sliver at the end
+                    sp.row_begin = a;
+                    sp.n_rows = b;
+                    const uint64_t rows = b - a;
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    int rcl;
+                    if (h->profile) { if ((rcl = event_pair(h, e0, e1))) return rcl; HIPOK(hipEventRecord(e0, h->stream)); }
+                    if (g_fold && radius < 0 && j.W == 1 && !j.mask) {
+                        // folded fast path + progressive threshold; the histogram it keeps must cover the rows collected so far
+                        if (!hist_live) { HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream)); hist_live = true; }
+                        launch_scan_fold(tq, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                    } else {
+                        launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                    }
+                    if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+                    h->stats.scan_launches += 1;
+                    h->stats.scan_passes += groups;
+                    h->stats.scan_bytes += rows * 8 * j.W * groups;
+                    a = b;
+                }
+                return 0;
+            };
+
             if (radius >= 0) {
                 // range-limited search: the threshold is given, so one streaming pass collects everything
                 hipLaunchKernelGGL(isk::radius_init_kernel, dim3((nq_pad + isk::BLOCK - 1) / isk::BLOCK), dim3(isk::BLOCK), 0, h->stream,
                                    h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)radius);
-                sp.row_begin = 0;
-                sp.n_rows = s.n;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
-                launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, s.n, groups), groups), h->stream, sp);
-                if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
-                h->stats.scan_launches += 1;
-                h->stats.scan_passes += groups;
-                h->stats.scan_bytes += s.n * 8 * j.W * groups;
+                if ((rc = collect_from(0))) return rc;
                 launch_select(c.sl, nq);
                 HIPOK(hipGetLastError());
                 continue;
@@ -496,13 +523,11 @@ struct Batch {
             //    it.  A level meets ~k * growth candidates per query, so the stretches grow geometrically (8x;
             //    64x when there are so few query groups that launch gaps outweigh candidate handling; less
             //    when k * growth would not fit the candidate buffer).  No row is read twice.
-            const uint64_t tile_rows = (uint64_t)tile_rows_for((int)j.W);
-            uint64_t growth = (groups <= 2 && k <= 64) ? 64 : 8;
+            uint64_t growth = (groups <= 2 && k <= 64) ? std::max<uint64_t>(64, h->level_growth) : h->level_growth;
             // a stretch `growth` times the rows seen so far brings ~growth * (rows at or under tau) candidates, and the
             // tie class at tau can make that 2.3x k (ratio of consecutive binomial tails): keep it inside the buffer
             while (growth > 2 && (uint64_t)k * growth * 5 / 2 > (uint64_t)cap * 9 / 10) growth /= 2;
             uint64_t done = 0;                    // rows [0, done) are collected and in the histogram
-            bool hist_live = false;
             uint64_t reach = s0;                  // the threshold in force comes from rows [0, reach)
             for (;;) {
                 uint64_t end = reach >= s.n / growth ? s.n : reach * growth;
@@ -525,25 +550,8 @@ struct Batch {
             }
             const uint64_t collected_to = done;
 
-            // 3. the streaming pass: collect every remaining row within the threshold
-            if (collected_to < s.n) {
-                sp.row_begin = collected_to;
-                sp.n_rows = s.n;
-                const uint64_t rows = s.n - collected_to;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
-                if (g_fold && j.W == 1 && !j.mask) {
-                    // folded fast path + progressive threshold; the histogram it keeps must cover the rows collected so far
-                    if (!hist_live) HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
-                    launch_scan_fold(tq, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
-                } else {
-                    launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
-                }
-                if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
-                h->stats.scan_launches += 1;
-                h->stats.scan_passes += groups;
-                h->stats.scan_bytes += rows * 8 * j.W * groups;
-            }
+            // 3. the collect pass over everything the levels have not covered
+            if ((rc = collect_from(collected_to))) return rc;
 
             // 4. exact select of the k best candidates per query (flags candidate-list overflow)
             launch_select(c.sl, nq);
@@ -794,7 +802,9 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "fold")) { g_fold = value != 0; return 0; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(-EINVAL, "blocks_per_cu must be 1..64"); h->blocks_per_cu = (uint32_t)value; return 0; }
     if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
-    if (!strcmp(name, "sample_cost")) { if (value < 1 || value > 10000) return fail(-EINVAL, "sample_cost must be 1..10000"); h->sample_cost = (uint64_t)value; return 0; }
+    if (!strcmp(name, "stretch_mb")) { if (value < 0 || value > 65536) return fail(-EINVAL, "stretch_mb must be 0..65536"); h->stretch_bytes = (uint64_t)value << 20; return 0; }
+    if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
+    if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
     return fail(-EINVAL, "unknown option '%s'", name);
 }
 
