@@ -289,7 +289,6 @@ void launch_scan_fold(int tq, dim3 grid, hipStream_t st, const isk::ScanParams& 
 template <int W, bool MASK, int TQ>
 void launch_scan_mode(int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     if (mode == isk::MODE_COLLECT) launch_scan_nt<W, MASK, TQ, isk::MODE_COLLECT>(nt, grid, st, p);
-    else if (mode == isk::MODE_HIST) launch_scan_nt<W, MASK, TQ, isk::MODE_HIST>(nt, grid, st, p);
     else launch_scan_nt<W, MASK, TQ, isk::MODE_BOTH>(nt, grid, st, p);
 }
 template <int W, bool MASK>
