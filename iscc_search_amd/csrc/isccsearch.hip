@@ -331,7 +331,10 @@ uint32_t scan_grid_x(H* h, int W, uint64_t rows, uint32_t groups = 1, bool sampl
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, maxb));
 }
 
+int drain_events(H* h);
 int event_pair(H* h, hipEvent_t& a, hipEvent_t& b) {
+    // a caller that profiles for a long time without reading the statistics must not grow the pool without bound
+    if (h->ev_used >= 4096) { int rc = drain_events(h); if (rc) return rc; }
     if (h->ev_used == h->ev_pool.size()) {
         hipEvent_t x, y;
         HIPOK(hipEventCreate(&x));
