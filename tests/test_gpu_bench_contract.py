@@ -1,0 +1,45 @@
+"""
+The driver's contract for ``bench.py``: ONE JSON line on stdout with the agreed keys, `roofline` and `cpu_baseline`
+objects included.  Runs the real script on a small index (2 M rows) so that it finishes in seconds.
+"""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    proc = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "2000000", "--steps", "3", "--warmup", "1", "--cpu-queries", "64"],
+        capture_output=True, text=True, timeout=600, cwd=ROOT,
+    )
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["unit"] == "queries/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert abs(out["value"] - 1024 / (out["ms_per_step"] / 1e3)) / out["value"] < 1e-6
+    assert "workload" in out["config"] and "model" not in out["config"]
+    roof = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["launches"] >= 3 and roof["avg_launch_ms"] > 0
+    cpu = out["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert out["roofline_streaming"]["bound"] == "hbm" and out["roofline_streaming"]["achieved"] > 0
