@@ -526,6 +526,7 @@ struct Batch {
             //    64x when there are so few query groups that launch gaps outweigh candidate handling; less
             //    when k * growth would not fit the candidate buffer).  No row is read twice.
             uint64_t growth = (groups <= 2 && k <= 64) ? std::max<uint64_t>(64, h->level_growth) : h->level_growth;
+            if (k >= 256) growth = std::min<uint64_t>(growth, 2);   // simprint-sized k: candidate handling dominates, +10 % with short levels
             // a stretch `growth` times the rows seen so far brings ~growth * (rows at or under tau) candidates, and the
             // tie class at tau can make that 2.3x k (ratio of consecutive binomial tails): keep it inside the buffer
             while (growth > 2 && (uint64_t)k * growth * 5 / 2 > (uint64_t)cap * 9 / 10) growth /= 2;
