@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nbytes", type=int, default=8, help="code length in bytes (8 = 64-bit)")
     ap.add_argument("--metric", choices=["hamming", "nphd"], default="hamming", help="table metric (nphd: every row --nbytes long, queries too)")
-    ap.add_argument("--tq", type=int, default=8, help="queries per streaming pass (8|10|12|16); 8 keeps the scan HBM-bound")
+    ap.add_argument("--tq", type=int, default=8, help="queries per pass (8|16); 8 keeps a streaming scan HBM-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
@@ -252,7 +252,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "scan_kernel<W=%d,COLLECT>" % words,
+            # the collect pass: scan_adapt_kernel<T_q, 3> for whole 64-bit codes, scan_kernel<W, mask, T_q, 3> otherwise
+            # (mode 3 = MODE_STRETCH; the threshold levels in front of it are mode 2 launches of the same code)
+            "kernel": ("scan_adapt_kernel<%d,STRETCH>" % args.tq) if words == 1 and args.nbytes % 8 == 0 else "scan_kernel<W=%d,STRETCH>" % words,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

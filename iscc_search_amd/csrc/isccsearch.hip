@@ -153,6 +153,8 @@ struct isccsearch_handle {
     uint32_t blocks_per_cu = 8;    // scan grid = CUs x this (per query group)
     uint64_t boot_rows = 4096;     // rows of the threshold bootstrap (exact histogram per query)
     uint64_t level_growth = 8;     // each threshold level streams this many times the rows seen so far
+    bool repick = true;            // re-derive the threshold after every collect stretch but the last
+    uint32_t fold_tau = 11;        // 64-bit codes: groups whose thresholds are all <= this take the folded fast path (0: off)
     uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
@@ -264,9 +266,6 @@ int ensure_index(H* h, Table& t) {
 // ------------------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------------------
-bool g_fold = false;  // OR-fold filter + progressive threshold for the streaming pass over whole 64-bit codes
-                      // (option "fold"; process-wide)
-
 template <int W, bool MASK, int TQ, int MODE>
 void launch_scan_nt(bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     // only the non-temporal variant is instantiated: plain loads measured no faster and
@@ -274,29 +273,16 @@ void launch_scan_nt(bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p
     (void)nt;
     hipLaunchKernelGGL((isk::scan_kernel<W, MASK, TQ, MODE, true>), grid, dim3(isk::BLOCK), 0, st, p);
 }
-// the streaming pass over whole 64-bit codes with the folded fast path under a progressively tightened threshold
-#ifndef ISK_EXP_FOLD
-#define ISK_EXP_FOLD true
-#endif
-void launch_scan_fold(int tq, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
-    switch (tq) {
-        case 8: hipLaunchKernelGGL((isk::scan_kernel<1, false, 8, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
-        case 10: hipLaunchKernelGGL((isk::scan_kernel<1, false, 10, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
-        case 12: hipLaunchKernelGGL((isk::scan_kernel<1, false, 12, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
-        default: hipLaunchKernelGGL((isk::scan_kernel<1, false, 16, isk::MODE_BOTH, true, ISK_EXP_FOLD, true>), grid, dim3(isk::BLOCK), 0, st, p); break;
-    }
-}
 template <int W, bool MASK, int TQ>
 void launch_scan_mode(int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     if (mode == isk::MODE_COLLECT) launch_scan_nt<W, MASK, TQ, isk::MODE_COLLECT>(nt, grid, st, p);
+    else if (mode == isk::MODE_STRETCH) launch_scan_nt<W, MASK, TQ, isk::MODE_STRETCH>(nt, grid, st, p);
     else launch_scan_nt<W, MASK, TQ, isk::MODE_BOTH>(nt, grid, st, p);
 }
 template <int W, bool MASK>
 void launch_scan_tq(int tq, int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
     switch (tq) {
         case 8: launch_scan_mode<W, MASK, 8>(mode, nt, grid, st, p); break;
-        case 10: launch_scan_mode<W, MASK, 10>(mode, nt, grid, st, p); break;
-        case 12: launch_scan_mode<W, MASK, 12>(mode, nt, grid, st, p); break;
         default: launch_scan_mode<W, MASK, 16>(mode, nt, grid, st, p); break;
     }
 }
@@ -305,7 +291,20 @@ void launch_scan_mask(bool mask, int tq, int mode, bool nt, dim3 grid, hipStream
     if (mask) launch_scan_tq<W, true>(tq, mode, nt, grid, st, p);
     else launch_scan_tq<W, false>(tq, mode, nt, grid, st, p);
 }
+template <int MODE>
+void launch_scan_adapt(int tq, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    switch (tq) {
+        case 8: hipLaunchKernelGGL((isk::scan_adapt_kernel<8, MODE>), grid, dim3(isk::BLOCK), 0, st, p); break;
+        default: hipLaunchKernelGGL((isk::scan_adapt_kernel<16, MODE>), grid, dim3(isk::BLOCK), 0, st, p); break;
+    }
+}
 void launch_scan(int W, bool mask, int tq, int mode, bool nt, dim3 grid, hipStream_t st, const isk::ScanParams& p) {
+    if (W == 1 && !mask && p.fold_tau) {   // whole 64-bit codes: the kernel picks its fast path per query group
+        if (mode == isk::MODE_COLLECT) launch_scan_adapt<isk::MODE_COLLECT>(tq, grid, st, p);
+        else if (mode == isk::MODE_STRETCH) launch_scan_adapt<isk::MODE_STRETCH>(tq, grid, st, p);
+        else launch_scan_adapt<isk::MODE_BOTH>(tq, grid, st, p);
+        return;
+    }
     switch (W) {
         case 1: launch_scan_mask<1>(mask, tq, mode, nt, grid, st, p); break;
         case 2: launch_scan_mask<2>(mask, tq, mode, nt, grid, st, p); break;
@@ -401,7 +400,7 @@ struct Batch {
         Ctx c{};
         for (uint32_t w = 0; w < j.W; ++w) c.sp.col[w] = s.col[w];
         c.sp.queries = h->d_queries.p; c.sp.bias = h->d_bias.p; c.sp.cnt = h->d_cnt.p; c.sp.cand = h->d_cand.p;
-        c.sp.ghist = h->d_ghist.p; c.sp.cap = cap; c.sp.k = k;
+        c.sp.ghist = h->d_ghist.p; c.sp.cap = cap; c.sp.k = k; c.sp.fold_tau = h->fold_tau;
         c.sp.mask_lo = (uint32_t)j.mask_last; c.sp.mask_hi = (uint32_t)(j.mask_last >> 32);
         c.sl.cnt = h->d_cnt.p; c.sl.cand = h->d_cand.p; c.sl.cap = cap; c.sl.keys = s.keys;
         c.sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
@@ -486,14 +485,24 @@ struct Batch {
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     int rcl;
                     if (h->profile) { if ((rcl = event_pair(h, e0, e1))) return rcl; HIPOK(hipEventRecord(e0, h->stream)); }
-                    if (g_fold && radius < 0 && j.W == 1 && !j.mask) {
-                        // folded fast path + progressive threshold; the histogram it keeps must cover the rows collected so far
+                    // every stretch but the last keeps the histogram and is followed by a pick, so the threshold keeps
+                    // tightening through the pass (free for k = 10, +2.5 % for k = 100; it is also what lets the
+                    // folded fast path of scan_adapt_kernel switch on as the pass advances)
+                    // (the last stretch keeps the histogram too -- a handful of atomics -- so that the whole pass is ONE
+                    // kernel instantiation, MODE_STRETCH; it just is not followed by a pick)
+                    const bool hist_too = h->repick && radius < 0;
+                    const bool repick = hist_too && b < s.n;
+                    if (hist_too) {
                         if (!hist_live) { HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream)); hist_live = true; }
-                        launch_scan_fold(tq, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                        launch_scan((int)j.W, j.mask, tq, isk::MODE_STRETCH, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
                     } else {
                         launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
                     }
                     if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+                    if (repick) {
+                        isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, b), h->d_cnt.p, h->d_cand.p, cap};
+                        hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
+                    }
                     h->stats.scan_launches += 1;
                     h->stats.scan_passes += groups;
                     h->stats.scan_bytes += rows * 8 * j.W * groups;
@@ -795,17 +804,19 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(name, "queries_per_pass")) {
         // 32 is not offered: its query registers spill to scratch, which the asm-issued loads forbid
-        if (value != 8 && value != 10 && value != 12 && value != 16) return fail(-EINVAL, "queries_per_pass must be 8, 10, 12 or 16");
+        if (value != 8 && value != 16) return fail(-EINVAL, "queries_per_pass must be 8 or 16");
         h->tq = (int)value;
         h->stats.queries_per_pass = (uint32_t)value;
         return 0;
     }
     if (!strcmp(name, "profile")) { h->profile = value != 0; return 0; }
     if (!strcmp(name, "nontemporal")) { h->nontemporal = value != 0; return 0; }
-    if (!strcmp(name, "fold")) { g_fold = value != 0; return 0; }
+    if (!strcmp(name, "fold")) { h->fold_tau = value ? 11 : 0; return 0; }   // shorthand kept from the experiments
     if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(-EINVAL, "blocks_per_cu must be 1..64"); h->blocks_per_cu = (uint32_t)value; return 0; }
     if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "stretch_mb")) { if (value < 0 || value > 65536) return fail(-EINVAL, "stretch_mb must be 0..65536"); h->stretch_bytes = (uint64_t)value << 20; return 0; }
+    if (!strcmp(name, "repick")) { h->repick = value != 0; return 0; }
+    if (!strcmp(name, "fold_tau")) { if (value < 0 || value > 32) return fail(-EINVAL, "fold_tau must be 0..32"); h->fold_tau = (uint32_t)value; return 0; }
     if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
     return fail(-EINVAL, "unknown option '%s'", name);

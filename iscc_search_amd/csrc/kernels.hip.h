@@ -44,7 +44,9 @@ constexpr uint32_t BIT31 = 0x80000000u;
 constexpr uint32_t BIAS_NEVER = 0x80000000u;  // bias + h always has bit 31 set: never a candidate
 constexpr int MODE_COLLECT = 0;   // append candidates
 constexpr int MODE_HIST = 1;      // count candidates per hamming distance
-constexpr int MODE_BOTH = 2;      // both (last sample level: its rows are not scanned again)
+constexpr int MODE_BOTH = 2;      // both: the threshold levels
+constexpr int MODE_STRETCH = 3;   // as MODE_BOTH, for the stretches of the collect pass: a separate instantiation so that
+                                  // profilers tell the pass from the levels by kernel name
 
 struct Record {            // == isccsearch_record (24 bytes)
     uint64_t key_hi;
@@ -77,13 +79,14 @@ struct ScanParams {
     uint64_t row_begin;       // first row scanned (a multiple of the tile size)
     uint64_t n_rows;          // rows [row_begin, n_rows) are scanned
     const uint64_t* queries;  // [nq_pad][4] big-endian packed query words
-    uint32_t* bias;           // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries); PROG scans tighten it
+    const uint32_t* bias;     // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries)
     uint32_t* cnt;            // [nq_pad * CNT_STRIDE] candidates appended so far (MODE_COLLECT)
     uint64_t* cand;           // [nq_pad][cap] (hamming << 48) | row          (MODE_COLLECT)
     uint32_t* ghist;          // [nq_pad][HB] histogram of hamming <= tau     (MODE_HIST)
     uint32_t cap;
     uint32_t mask_lo, mask_hi;  // mask of the last compared word (partial-word prefixes)
-    uint32_t k;                 // results wanted per query (PROG scans: the threshold follows the k-th best so far)
+    uint32_t k;                 // results wanted per query
+    uint32_t fold_tau;          // scan_adapt_kernel: groups whose thresholds are all <= this take the folded fast path (0: never)
 };
 
 __device__ __forceinline__ uint32_t bcnt(uint32_t x, uint32_t acc) {
@@ -182,35 +185,12 @@ __device__ __forceinline__ void wait_tile(u32x4 (&v)[U][W]) {
 template <int MODE>
 __device__ __forceinline__ uint32_t emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
     uint32_t slot = 0;
-    if constexpr (MODE == MODE_COLLECT || MODE == MODE_BOTH) {
+    if constexpr (MODE == MODE_COLLECT || MODE == MODE_BOTH || MODE == MODE_STRETCH) {
         slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
         if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)h << 48) | row;
     }
-    if constexpr (MODE == MODE_HIST || MODE == MODE_BOTH) atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
+    if constexpr (MODE == MODE_HIST || MODE == MODE_BOTH || MODE == MODE_STRETCH) atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
     return slot;
-}
-
-// Progressive threshold (PROG scans): ghist[q] counts every row seen so far per distance and is complete for all
-// bins <= the current tau (tau only ever decreases).  Once the bins 0..t hold k rows for some t < tau, no row
-// further than t can reach the top k: publish the tighter threshold.  Called by lanes that just appended a
-// candidate (rare), so the <= tau loads do not matter.
-__device__ __forceinline__ void tighten(const ScanParams& p, uint32_t qi, uint32_t bias_now) {
-    const uint32_t tau = 0x7FFFFFFFu - bias_now;       // <= 64: PROG scans cover whole 64-bit codes only
-    const uint32_t* hq = p.ghist + (uint64_t)qi * HB;
-    uint32_t cum = 0;
-    for (uint32_t base = 0; base < tau; base += 16) {
-        // sixteen bins per round trip: the loads bypass the caches (agent scope), one dependent load per bin
-        // would stall the wave for ~tau memory latencies
-        uint32_t v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(hq + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (base + i >= tau) return;
-            cum += v[i];
-            if (cum >= p.k) { atomicMax(&p.bias[qi], 0x7FFFFFFFu - (base + i)); return; }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,13 +202,11 @@ __device__ __forceinline__ void tighten(const ScanParams& p, uint32_t qi, uint32
 //   minimum.  Only lanes whose minimum has bit 31 clear enter the (rare) emit path.
 // ---------------------------------------------------------------------------------------------
 //   FOLD: the fast path tests popc((lo^q_lo)|(hi^q_hi)) <= tau, a NECESSARY condition, for 3.5 instead of 4.5 ops
-//         per pair; the emit path computes the exact distance.  Only pays under a tight threshold, hence
-//   PROG: the SGPR thresholds are refreshed from p.bias every two tiles while emitters tighten p.bias to the
-//         k-th best distance seen so far (MODE_BOTH: the histogram is the bookkeeping).
-template <int W, bool MASK, int TQ, int MODE, bool NT, bool FOLD = false, bool PROG = false>
-__global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
+//         per pair; the emit path computes the exact distance.  Only pays under a tight threshold: chosen at run
+//         time by scan_adapt_kernel.
+template <int W, bool MASK, int TQ, int MODE, bool NT, bool FOLD = false>
+__device__ __forceinline__ void scan_body(const ScanParams& p) {
     static_assert(!FOLD || (W == 1 && !MASK), "the OR-fold filter is for whole 64-bit codes");
-    static_assert(!PROG || MODE == MODE_BOTH, "the progressive threshold needs the candidate histogram");
     constexpr int U = TileCfg<W>::U;
     constexpr int TILE = BLOCK * 2 * U;
     constexpr bool QL = queries_in_lds<W, TQ>() && !FOLD;
@@ -371,14 +349,12 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
                     mq = min(mq, min(a0, a1));
                 }
                 if ((int32_t)mq >= 0) {
-                    bool look = false;     // PROG: every 8th candidate of a query re-derives the threshold
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const uint64_t row = base + (uint64_t)u * 128;
-                        if ((int32_t)a[u][0] >= 0) look |= (emit<MODE>(p, q0 + q, a[u][0] - bias[q], row) & 7u) == 7u;
-                        if ((int32_t)a[u][1] >= 0) look |= (emit<MODE>(p, q0 + q, a[u][1] - bias[q], row + 1) & 7u) == 7u;
+                        if ((int32_t)a[u][0] >= 0) emit<MODE>(p, q0 + q, a[u][0] - bias[q], row);
+                        if ((int32_t)a[u][1] >= 0) emit<MODE>(p, q0 + q, a[u][1] - bias[q], row + 1);
                     }
-                    if constexpr (PROG) { if (look) tighten(p, q0 + q, bias[q]); }
                 }
             }
         }
@@ -396,18 +372,10 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
             const uint64_t last = n_full - 1;
             load_tile(va, tile);
             for (;;) {
-                // PROG: fetch the live thresholds (agent scope: past the CU's L1) BEFORE the prefetch is issued, so
-                // the counted wait below still sees exactly U*W younger loads; consumed after the tile is scored
-                uint32_t live = 0;
-                if constexpr (PROG) live = __hip_atomic_load(&p.bias[q0 + lane % TQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint64_t t1 = tile + gridDim.x;
                 load_tile(vb, t1 < n_full ? t1 : last);
                 wait_tile<U * W>(va);
                 process(va, tile);
-                if constexpr (PROG) {
-#pragma unroll
-                    for (int q = 0; q < TQ; ++q) bias[q] = __builtin_amdgcn_readlane(live, q);
-                }
                 if (t1 >= n_full) break;
                 const uint64_t t2 = t1 + gridDim.x;
                 load_tile(va, t2 < n_full ? t2 : last);
@@ -472,6 +440,26 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
             }
         }
     }
+}
+
+template <int W, bool MASK, int TQ, int MODE, bool NT>
+__global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanParams p) {
+    scan_body<W, MASK, TQ, MODE, NT, false>(p);
+}
+
+// Whole 64-bit codes: both fast paths in one kernel, chosen per query group at run time.  The folded path saves one
+// VALU operation per pair but raises a false alarm (a full rescoring of the tile) for ~3.8e-5 of the pairs at
+// tau = 13, 8e-6 at 12, 1.5e-6 at 11 (y = (lo^q_lo)|(hi^q_hi) is Binomial(32, 3/4) for unrelated codes): it pays
+// only once the group's thresholds are tight -- which the levels and the picks between stretches bring about as
+// the pass advances, and which a collision lookup (max_hamming 0) has from the start.
+template <int TQ, int MODE>
+__global__ __launch_bounds__(BLOCK) void scan_adapt_kernel(const ScanParams p) {
+    const uint32_t q0 = blockIdx.y * TQ;
+    bool fold = p.fold_tau != 0;
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) fold = fold && sgpr(p.bias[q0 + q]) >= 0x7FFFFFFFu - p.fold_tau;   // BIAS_NEVER passes too
+    if (fold) scan_body<1, false, TQ, MODE, true, true>(p);
+    else scan_body<1, false, TQ, MODE, true, false>(p);
 }
 
 // ---------------------------------------------------------------------------------------------

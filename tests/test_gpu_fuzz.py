@@ -46,7 +46,7 @@ def test_random_operation_sequences(hip_engine, seed):
     key_words = int(rng.integers(1, 3))
     max_bytes = int(rng.choice([1, 3, 8, 12, 16, 24, 32]))
     mw = (max_bytes + 7) // 8
-    tq = int(rng.choice([8, 10, 12, 16]))
+    tq = int(rng.choice([8, 16]))
     hip_engine.set_option("queries_per_pass", tq)
     t = hip_engine.open_table(metric, key_words, max_bytes)
     model = OracleTable(metric, key_words, max_bytes)

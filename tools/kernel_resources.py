@@ -14,9 +14,14 @@ scr_key = "ScratchSize \\[bytes/lane\\]"
 for b in re.split(r"Function Name: ", txt)[1:]:
     name = b.split()[0]
     m = re.match(r"_ZN3isk11scan_kernelILi(\d)ELb(\d)ELi(\d+)ELi(\d)ELb1E", name)
-    if not m:
-        continue
-    W, MASK, TQ, MODE = m.groups()
+    if m:
+        W, MASK, TQ, MODE = m.groups()
+    else:
+        m = re.match(r"_ZN3isk17scan_adapt_kernelILi(\d+)ELi(\d)E", name)   # 64-bit codes, both fast paths in one kernel
+        if not m:
+            continue
+        W, MASK = "1*", "0"
+        TQ, MODE = m.groups()
 
     def g(k):
         return re.search(k + r": (\d+)", b).group(1)
