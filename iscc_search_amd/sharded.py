@@ -120,7 +120,13 @@ class ShardedTable:
             return self.ops.merge(block, 1, nq, k)
         import torch
 
-        gathered = torch.empty(self.world_size * block.numel(), dtype=block.dtype, device=block.device)
-        # the one exchange step of the path: [world] x {records [nq][k] | counts [nq]}
-        self.dist.all_gather_into_tensor(gathered, block, group=self.group)
+        if block.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsal transport (several ranks sharing one GPU cannot use RCCL): stage the blocks through the host
+            host = torch.empty(self.world_size * block.numel(), dtype=block.dtype)
+            self.dist.all_gather_into_tensor(host, block.cpu(), group=self.group)
+            gathered = host.to(block.device)
+        else:
+            gathered = torch.empty(self.world_size * block.numel(), dtype=block.dtype, device=block.device)
+            # the one exchange step of the path: [world] x {records [nq][k] | counts [nq]}
+            self.dist.all_gather_into_tensor(gathered, block, group=self.group)
         return self.ops.merge(gathered, self.world_size, nq, k)

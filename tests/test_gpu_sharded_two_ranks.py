@@ -1,0 +1,71 @@
+"""
+Two PROCESSES, each with its own engine and its own row-range shard on the (one) GPU of the box, driving the product
+``ShardedTable`` + ``HipShardOps``: local device search, exchange, device merge.  The exchange runs over gloo (ranks
+that share a GPU cannot form an RCCL communicator), staged through the host by ``ShardedTable``; everything else is
+the code path of the multi-GPU deployment.  Every rank must hold exactly the unsharded answer.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROWS, SEED, NQ, K = 3_000_000, 0x1511CC00, 24, 10
+
+
+def _queries():
+    rng = np.random.default_rng(5)
+    return rng.integers(0, 2**64, size=(NQ, 1), dtype=np.uint64)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from iscc_search_amd.engine import HipEngine
+    from iscc_search_amd.sharded import HipShardOps, ShardedTable, shard_range
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    engine = HipEngine(0)
+    try:
+        lo, hi = shard_range(ROWS, rank, world)
+        table = engine.open_table(0, 1, 8)
+        table.add_synthetic(8, hi - lo, SEED, first_row=lo)
+        sharded = ShardedTable(HipShardOps(table, "cuda:0"))
+        q = _queries()
+        out = {}
+        for i, a in enumerate(sharded.search(q, None, K)):
+            out[f"s{i}"] = a
+        for i, a in enumerate(sharded.search_within(q, None, 50, 14)):
+            out[f"w{i}"] = a
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), **out)
+    finally:
+        engine.close()
+        dist.destroy_process_group()
+
+
+def test_two_processes_two_shards_one_gpu(hip_engine, tmp_path):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    whole = hip_engine.open_table(0, 1, 8)
+    try:
+        whole.add_synthetic(8, ROWS, SEED)
+        q = _queries()
+        want_s = whole.search(q, None, K)
+        want_w = whole.search_within(q, None, 50, 14)
+        for rank in range(2):
+            with np.load(os.path.join(tmp_path, f"r{rank}.npz")) as z:
+                for i in range(4):
+                    np.testing.assert_array_equal(z[f"s{i}"], want_s[i], err_msg=f"rank {rank} search field {i}")
+                    np.testing.assert_array_equal(z[f"w{i}"], want_w[i], err_msg=f"rank {rank} within field {i}")
+        assert int(want_w[3].sum()) > 0          # the radius admits rows, so the within lists are not trivially empty
+    finally:
+        whole.drop()
