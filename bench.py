@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
     ap.add_argument("--no-streaming-check", action="store_true", help="skip the extra HBM-streaming measurement (stretch_mb=0) after the timed region")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0 and the process group runs over gloo "
+                         "(ranks sharing a GPU cannot form an RCCL communicator); the number it prints is not a scaling result")
     ap.add_argument("--force-collective", action="store_true", help="initialise RCCL and run the all-gather even with one rank (rehearsal)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     args = ap.parse_args()
@@ -98,6 +101,8 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_collective:
@@ -110,7 +115,10 @@ def main():
                 os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     words = (args.nbytes + 7) // 8
     engine = HipEngine(local_rank)
