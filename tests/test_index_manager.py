@@ -226,6 +226,24 @@ def test_instance_units_match_by_prefix_both_ways(manager, rng):
         assert all(t == {"INSTANCE_NONE_V0": 1.0} for t in got.values())
 
 
+def test_single_unit_helpers_agree_with_the_batched_path(manager, rng):
+    """``_search_similarity_unit`` / ``_search_instance_unit`` (the reference's per-unit methods, usearch/index.py:2024-2045,
+    :1957-2022) return what ``_search_units`` (one engine call for all units of a request) merges."""
+    manager.create_index(IsccIndex(name="t"))
+    assets = [make_asset(rng, i, bits=128) for i in range(30)]
+    manager.add_assets("t", assets)
+    idx = manager._index("t")
+    units = assets[3].units
+    merged = idx._search_units(units, 10)
+    for unit_str in units:
+        unit = codec.Iscc(unit_str)
+        if unit.unit_type.startswith("INSTANCE_"):
+            single = idx._search_instance_unit(unit.unit_type, unit.body)
+        else:
+            single = idx._search_similarity_unit(unit.unit_type, unit.body, 10)
+        assert single == {key: types[unit.unit_type] for key, types in merged.items() if unit.unit_type in types}
+
+
 def test_units_only_query_and_isolation(manager, rng):
     manager.create_index(IsccIndex(name="a"))
     manager.create_index(IsccIndex(name="b"))
