@@ -449,6 +449,10 @@ class HipIndexManager:
     The engine (library load, GPU context, stream) is created lazily on first use and released by
     ``close()``, which is idempotent (``protocols/index.py:162-172``).  Thread-safe: FastAPI calls
     the sync protocol methods from a thread pool (``docs/explanation/architecture.md:120-126``).
+
+    ``engine`` is a seam for sharing one ``HipEngine`` between managers and for the CPU test tier (which injects
+    an oracle-backed stand-in from ``tests/``); left ``None`` -- as ``get_index("hip:///")`` leaves it -- the manager
+    creates a ``HipEngine`` and raises if the HIP library or the GPU is missing.  There is no CPU fallback.
     """
 
     def __init__(self, uri="hip:///", engine=None, options=None):
