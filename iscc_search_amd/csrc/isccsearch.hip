@@ -1566,26 +1566,27 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
     }
     HIPOK(hipStreamSynchronize(h->stream));
 
-    // pass 3: hand out the results; overflowed and non-deferred requests run the ordinary pipeline
+    // pass 3a: hand out EVERY deferred result first.  The ordinary pipeline below stages its own results in p_block
+    // from offset 0 (and may reallocate it), so no deferred slice may still be unread when it runs.
+    std::vector<bool> ordinary(n, false);
     for (uint32_t i = 0; i < n; ++i) {
         isccsearch_request& r = reqs[i];
         if (r.status || r.nq == 0) continue;
-        bool ordinary = !deferred[i];
-        if (deferred[i]) {
-            Batch& b = *slots[i].batch;
-            if (!b.jobs.empty() && b.any_flag()) ordinary = true;     // rare: exact fallback through the normal path
-            else {
-                const isk::Record* p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p + slots[i].block_off);
-                const uint32_t* p_cnt = reinterpret_cast<const uint32_t*>(h->p_block.p + slots[i].block_off + slots[i].rec_bytes);
-                unpack_records(p_rec, p_cnt, r.nq, r.k, h->tables[r.table]->key_words, nullptr, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count);
-            }
-        }
-        if (ordinary) {
-            if (!deferred[i]) h->stats.searches += 1;
-            rc = search_locked(h, r.table, r.nq, r.q_words, r.q_nbytes, r.k, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count,
-                               r.max_hamming < 0 ? -1 : r.max_hamming);
-            if (rc) reject(r, rc);
-        }
+        if (!deferred[i]) { ordinary[i] = true; continue; }
+        Batch& b = *slots[i].batch;
+        if (!b.jobs.empty() && b.any_flag()) { ordinary[i] = true; continue; }   // rare: exact fallback through the normal path
+        const isk::Record* p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p + slots[i].block_off);
+        const uint32_t* p_cnt = reinterpret_cast<const uint32_t*>(h->p_block.p + slots[i].block_off + slots[i].rec_bytes);
+        unpack_records(p_rec, p_cnt, r.nq, r.k, h->tables[r.table]->key_words, nullptr, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count);
+    }
+    // pass 3b: overflowed and non-deferred requests run the ordinary pipeline
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!ordinary[i]) continue;
+        isccsearch_request& r = reqs[i];
+        if (!deferred[i]) h->stats.searches += 1;
+        rc = search_locked(h, r.table, r.nq, r.q_words, r.q_nbytes, r.k, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count,
+                           r.max_hamming < 0 ? -1 : r.max_hamming);
+        if (rc) reject(r, rc);
     }
     return first_error;
 }

@@ -1,13 +1,15 @@
 """
 ``isccsearch_search_many``: several searches, one synchronisation.  Every request must return exactly what the
-single-request entry points return (they are checked against the oracle elsewhere), whichever internal path
-it takes: deferred (single-segment table), ordinary (multi-segment / mixed query lengths / empty table), or the
-exact fallback after a candidate-list overflow.
+ORACLE returns for it (an ``OracleTable`` mirror holds the same rows as each device table), whichever internal
+path it takes: deferred (single-segment table), ordinary (multi-segment / mixed query lengths / empty table), or
+the exact fallback after a candidate-list overflow -- and in whichever ORDER the paths are mixed: the ordinary
+pipeline stages its results in the same pinned block the deferred requests were copied into.
 """
 
 import numpy as np
 import pytest
 
+from oracle_engine import OracleTable
 from test_gpu_parity import METRIC_HAMMING, METRIC_NPHD, _mask_to_len, _rand_words
 
 pytestmark = pytest.mark.gpu
@@ -18,13 +20,38 @@ def _same(a, b, tag):
         np.testing.assert_array_equal(x, y, err_msg=f"{tag}: {name}")
 
 
-def test_search_many_equals_single_calls(hip_engine):
+class Mirrored:
+    """A device table and an oracle table holding the same rows."""
+
+    def __init__(self, engine, metric, key_words, max_bytes):
+        self.hip = engine.open_table(metric, key_words, max_bytes)
+        self.ref = OracleTable(metric, key_words, max_bytes)
+
+    def add(self, keys, words, nbytes=None):
+        self.hip.add(keys, words, nbytes)
+        self.ref.add(keys, words, nbytes)
+
+    def expect(self, q, nb, k, radius):
+        return self.ref.search(q, nb, k) if radius is None else self.ref.search_within(q, nb, k, radius)
+
+    def drop(self):
+        self.hip.drop()
+
+
+def _run_and_check(engine, plan, tag):
+    got = engine.search_many([(m.hip, q, nb, k, r) for m, q, nb, k, r in plan])
+    for i, ((m, q, nb, k, r), g) in enumerate(zip(plan, got)):
+        _same(g, m.expect(q, nb, k, r), f"{tag} request {i}")
+    return got
+
+
+def test_search_many_equals_the_oracle_in_every_order(hip_engine):
     rng = np.random.default_rng(77)
-    t1 = hip_engine.open_table(METRIC_HAMMING, 1, 8)
-    t2 = hip_engine.open_table(METRIC_NPHD, 1, 32)
-    t3 = hip_engine.open_table(METRIC_HAMMING, 2, 16)
-    t4 = hip_engine.open_table(METRIC_NPHD, 1, 32)      # one segment only: deferred even though it is an NPHD table
-    empty = hip_engine.open_table(METRIC_HAMMING, 1, 8)
+    t1 = Mirrored(hip_engine, METRIC_HAMMING, 1, 8)
+    t2 = Mirrored(hip_engine, METRIC_NPHD, 1, 32)
+    t3 = Mirrored(hip_engine, METRIC_HAMMING, 2, 16)
+    t4 = Mirrored(hip_engine, METRIC_NPHD, 1, 32)      # one segment only: deferred even though it is an NPHD table
+    empty = Mirrored(hip_engine, METRIC_HAMMING, 1, 8)
     try:
         n = 30000
         w1 = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
@@ -55,13 +82,21 @@ def test_search_many_equals_single_calls(hip_engine):
             (t4, q4, nb32, 20, None),          # single-segment NPHD table: deferred
             (t1, w1[:1], None, 10, 0),         # 400 collisions asked for 10: still fits the candidate list
         ]
-        got = hip_engine.search_many(requests)
-        for i, ((table, q, nb, k, r), g) in enumerate(zip(requests, got)):
-            want = table.search(q, nb, k) if r is None else table.search_within(q, nb, k, r)
-            _same(g, want, f"request {i}")
+        _run_and_check(hip_engine, requests, "mixed")
+        # the orders ADVICE r1 names: an ordinary (multi-segment) request AHEAD of a deferred one, and a large
+        # ordinary request (nq * k records from offset 0 of the staging block) between two small deferred ones
+        _run_and_check(hip_engine, [requests[1], requests[0]], "ordinary-then-deferred")
+        _run_and_check(hip_engine, [requests[4], requests[6], requests[1], requests[2]], "ordinary-deferred-ordinary-deferred")
+        q2_many = _mask_to_len(w2[rng.integers(0, n, size=40)].copy(), np.full(40, 16, dtype=np.uint8))
+        big_ordinary = (t2, q2_many, np.full(40, 16, np.uint8), 300, None)
+        _run_and_check(hip_engine, [(t1, q1[:1], None, 3, None), big_ordinary, (t4, q4, nb32, 5, None), (t1, q1, None, 10, None)],
+                       "deferred-small / ordinary-large / deferred")
+        # search_assets' own shape: a mixed-length META table ahead of a single-length CONTENT table (index.py::_search_units)
+        _run_and_check(hip_engine, [(t2, q2_mixed[:1], nbmix[:1], 100, None), (t4, q4[:1], nb32[:1], 100, None), (t1, q1[:1], None, 4096, 0)],
+                       "search_assets shape")
         assert hip_engine.search_many([]) == []
         with pytest.raises(ValueError):
-            hip_engine.search_many([(t1, q1, None, 0, None)])
+            hip_engine.search_many([(t1.hip, q1, None, 0, None)])
     finally:
         for t in (t1, t2, t3, t4, empty):
             t.drop()
@@ -69,17 +104,21 @@ def test_search_many_equals_single_calls(hip_engine):
 
 def test_search_many_overflow_takes_the_exact_fallback(hip_engine):
     n = 120000
-    t = hip_engine.open_table(METRIC_HAMMING, 1, 8)
+    t = Mirrored(hip_engine, METRIC_HAMMING, 1, 8)
+    small = Mirrored(hip_engine, METRIC_HAMMING, 1, 8)
     try:
         words = np.full((n, 1), 0x1111111111111111, dtype=np.uint64)
         words[::3] ^= np.uint64(1)
         t.add(np.arange(n, dtype=np.uint64)[::-1].copy() + np.uint64(5), words)
+        rng = np.random.default_rng(4)
+        sw = rng.integers(0, 2**64, size=(5000, 1), dtype=np.uint64)
+        small.add(np.arange(5000, dtype=np.uint64) + np.uint64(1), sw)
         q = np.array([[0x1111111111111111], [0x1111111111111110], [0x7777777777777777]], dtype=np.uint64)
         before = hip_engine.stats()["fallback_queries"]
-        got = hip_engine.search_many([(t, q, None, 10, None), (t, q, None, 50, 0), (t, q[:1], None, 5, None)])
+        # the overflowed requests rerun through the ordinary path AFTER every deferred result has been handed out,
+        # the healthy deferred request behind them included
+        _run_and_check(hip_engine, [(t, q, None, 10, None), (t, q, None, 50, 0), (t, q[:1], None, 5, None), (small, sw[:4], None, 7, None)], "overflow")
         assert hip_engine.stats()["fallback_queries"] > before
-        _same(got[0], t.search(q, None, 10), "plain")
-        _same(got[1], t.search_within(q, None, 50, 0), "within")
-        _same(got[2], t.search(q[:1], None, 5), "third")
     finally:
         t.drop()
+        small.drop()

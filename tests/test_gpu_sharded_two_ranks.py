@@ -2,7 +2,7 @@
 Two PROCESSES, each with its own engine and its own row-range shard on the (one) GPU of the box, driving the product
 ``ShardedTable`` + ``HipShardOps``: local device search, exchange, device merge.  The exchange runs over gloo (ranks
 that share a GPU cannot form an RCCL communicator), staged through the host by ``ShardedTable``; everything else is
-the code path of the multi-GPU deployment.  Every rank must hold exactly the unsharded answer.
+the code path of the multi-GPU deployment.  Every rank must hold exactly the ORACLE's answer over the unsharded rows.
 """
 
 import os
@@ -48,24 +48,27 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_processes_two_shards_one_gpu(hip_engine, tmp_path):
+def test_two_processes_two_shards_one_gpu(tmp_path):
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    whole = hip_engine.open_table(0, 1, 8)
-    try:
-        whole.add_synthetic(8, ROWS, SEED)
-        q = _queries()
-        want_s = whole.search(q, None, K)
-        want_w = whole.search_within(q, None, 50, 14)
-        for rank in range(2):
-            with np.load(os.path.join(tmp_path, f"r{rank}.npz")) as z:
-                for i in range(4):
-                    np.testing.assert_array_equal(z[f"s{i}"], want_s[i], err_msg=f"rank {rank} search field {i}")
-                    np.testing.assert_array_equal(z[f"w{i}"], want_w[i], err_msg=f"rank {rank} within field {i}")
-        assert int(want_w[3].sum()) > 0          # the radius admits rows, so the within lists are not trivially empty
-    finally:
-        whole.drop()
+    from oracle import np_within, oracle_splitmix64_fill, oracle_topk
+
+    words = oracle_splitmix64_fill(ROWS, SEED, stride=4).reshape(ROWS, 1)
+    row_keys = np.arange(ROWS, dtype=np.uint64)
+    q = _queries()
+    want_s = oracle_topk(0, row_keys, words, None, q, None, K)
+    want_w = (np.zeros((NQ, 50), np.uint64), np.zeros((NQ, 50), np.uint32), np.zeros((NQ, 50), np.uint16), np.zeros(NQ, np.uint32))
+    for i in range(NQ):
+        kk, h, p = np_within(words, 8, row_keys, q[i], 8, 50, 14)
+        c = len(h)
+        want_w[0][i, :c], want_w[1][i, :c], want_w[2][i, :c], want_w[3][i] = kk, h, p, c
+    for rank in range(2):
+        with np.load(os.path.join(tmp_path, f"r{rank}.npz")) as z:
+            for i in range(4):
+                np.testing.assert_array_equal(z[f"s{i}"], want_s[i], err_msg=f"rank {rank} search field {i}")
+                np.testing.assert_array_equal(z[f"w{i}"], want_w[i], err_msg=f"rank {rank} within field {i}")
+    assert int(want_w[3].sum()) > 0          # the radius admits rows, so the within lists are not trivially empty

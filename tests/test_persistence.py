@@ -14,6 +14,7 @@ from helpers import flip_bits, make_asset, sp
 from iscc_search_amd import codec
 from iscc_search_amd.index import HipIndexManager
 from iscc_search_amd.schema import IsccIndex, IsccQuery
+from oracle import oracle_topk
 from oracle_engine import OracleEngine
 
 
@@ -60,8 +61,11 @@ def test_table_roundtrip_files_and_results(engine, tmp_path):
     q = words[[1, 50, 999]].copy()
     q[:, 0] ^= np.uint64(6)
     qn = lens[[1, 50, 999]]
-    for a, b in zip(t.search(q, qn, 12), t2.search(q, qn, 12)):
-        np.testing.assert_array_equal(a, b)
+    # both the original and the reloaded table against the oracle on the arrays they were built from
+    want = oracle_topk(1, keys, words, lens, q, qn, 12)
+    for name, tbl in (("saved", t), ("reloaded", t2)):
+        for a, b, field in zip(tbl.search(q, qn, 12), want, ("keys", "hamming", "prefix_bits", "count")):
+            np.testing.assert_array_equal(a, b, err_msg=f"{name} table: {field}")
     # restored tables are fully mutable again
     assert t2.contains(keys[:3]).all() and t2.remove(keys[:3]) == 3 and t2.size == n - 3
     wrong = engine.open_table(0, 1, 8)

@@ -1,0 +1,255 @@
+// proto_mfma_scan.hip -- experiment: the collect scan of 64-bit codes as an int8 MFMA contraction.
+//
+//   hamming(row, q) = popc(q) + dot(row bits as 0/1, query bits as +1/-1)       (exact integers)
+//
+// A wave owns a 32-row tile: each lane expands ITS 32 bits of one row into 32 bytes of 0/1 (8 VGPRs = the A
+// operands of two v_mfma_i32_32x32x32_i8), once per tile, and then walks ALL query groups of the block: a group is
+// 32 queries pre-expanded to +1/-1 bytes in LDS (2 KB: two ds_read_b128 per lane), 2 MFMAs give the 32 x 32 dot
+// products, 8 v_min3_i32 fold a lane's 16 results (all of ONE query: C/D column = lane & 31) and one compare against
+// thr_q = tau_q - popc(q) decides whether the lane enters the rare emit path.  Rows cross the memory system once
+// per 1 024 queries; the bound is the matrix pipe (64 cycles per 1 024 pairs per SIMD) instead of 4.5 VALU
+// lane-operations per pair.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o proto_mfma_scan proto_mfma_scan.hip
+// Run  : ./proto_mfma_scan [rows] [queries] [tau] [blocks_per_cu]     (prints ms, pairs/s, check vs a brute-force kernel)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+__global__ void fill(uint64_t* col, uint64_t n, uint64_t seed) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        col[i] = splitmix64(seed + 4 * i);
+}
+
+struct P {
+    const uint64_t* col;
+    uint64_t n_rows;          // multiple of 32 in this prototype
+    const uint64_t* queries;  // [nq]
+    const int* tau;           // [nq]
+    uint32_t* cnt;            // [nq] candidates per query
+    uint64_t* cand;           // [nq][cap]
+    uint32_t cap;
+    uint32_t nq;              // multiple of 32
+};
+
+// brute force reference: hits per query + an order-independent checksum of (h, row)
+__global__ __launch_bounds__(256) void brute(P p, unsigned long long* sum) {
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < p.n_rows; r += (uint64_t)gridDim.x * 256) {
+        const uint64_t c = p.col[r];
+        for (uint32_t q = 0; q < p.nq; ++q) {
+            const int h = __popcll(c ^ p.queries[q]);
+            if (h <= p.tau[q]) {
+                atomicAdd(&p.cnt[q], 1u);
+                atomicAdd(&sum[q], (unsigned long long)splitmix64(((uint64_t)h << 48) | r));
+            }
+        }
+    }
+}
+
+__global__ void checksum(P p, unsigned long long* sum) {
+    const uint32_t q = blockIdx.x;
+    const uint32_t c = p.cnt[q] < p.cap ? p.cnt[q] : p.cap;
+    unsigned long long s = 0;
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) s += splitmix64(p.cand[(uint64_t)q * p.cap + i]);
+    atomicAdd(&sum[q], s);
+}
+
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+
+// LDS image: B fragments [G][2][64] v4i (group, mfma, lane) | thr[nq] | popc[nq]
+template <int GROUPS>
+__global__ __launch_bounds__(256) void mfma_scan(const P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v4i* lb = reinterpret_cast<v4i*>(smem);
+    int* lthr = reinterpret_cast<int*>(smem + (size_t)GROUPS * 2 * 64 * 16);
+    int* lpop = lthr + GROUPS * 32;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+
+    // prologue: expand the block's queries.  dword d_j = (x >> j) & 0x01010101 holds bits j, j+8, j+16, j+24 of the
+    // lane half's 32 bits as bytes 0/1; MFMA (j >> 2) takes it as VGPR (j & 3).  +1/-1: 0x01 | (d * 0xFE).
+    for (uint32_t i = tid; i < (uint32_t)GROUPS * 32 * 2; i += 256) {
+        const uint32_t q = i >> 1, hh = i & 1;
+        const uint64_t qw = p.queries[q];
+        const uint32_t x = hh ? (uint32_t)(qw >> 32) : (uint32_t)qw;
+        const uint32_t g = q >> 5, c = q & 31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t d = (x >> j) & 0x01010101u;
+            reinterpret_cast<uint32_t*>(&lb[((size_t)g * 2 + (j >> 2)) * 64 + hh * 32 + c])[j & 3] = 0x01010101u | (d * 0xFEu);
+        }
+        if (hh == 0) {
+            const int pc = __popcll(qw);
+            lpop[q] = pc;
+            lthr[q] = p.tau[q] - pc;
+        }
+    }
+    __syncthreads();
+
+    const uint64_t ntiles = p.n_rows / 32;
+    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    const uint32_t* col32 = reinterpret_cast<const uint32_t*>(p.col);
+    uint64_t tile = (uint64_t)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+
+    // a lane's 16 results of a group all belong to query g*32 + (lane & 31): fold them, compare once
+    auto reduce = [&](const v16i& acc, int thr, int g, uint64_t t) {
+        int m = min3i(acc[0], acc[1], acc[2]);
+        m = min3i(m, acc[3], acc[4]);
+        m = min3i(m, acc[5], acc[6]);
+        m = min3i(m, acc[7], acc[8]);
+        m = min3i(m, acc[9], acc[10]);
+        m = min3i(m, acc[11], acc[12]);
+        m = min3i(m, acc[13], acc[14]);
+        m = min(m, acc[15]);
+        if (__builtin_expect(m <= thr, 0)) {
+            // rare: row of result `reg` = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), query = g * 32 + (lane & 31)
+            const uint32_t q = g * 32 + r;
+            const int pc = lpop[q];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                if (acc[reg] <= thr) {
+                    const uint64_t row = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const uint32_t hd = (uint32_t)(acc[reg] + pc);
+                    const uint32_t slot = atomicAdd(&p.cnt[q], 1u);
+                    if (slot < p.cap) p.cand[(uint64_t)q * p.cap + slot] = ((uint64_t)hd << 48) | row;
+                }
+            }
+        }
+    };
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto mm = [&](const v4i& a0, const v4i& a1, const v4i& b0, const v4i& b1) {
+        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, zero, 0, 0, 0);
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc, 0, 0, 0);
+    };
+    const v4i* lbl = lb + lane;
+    const int* lt = lthr + r;
+
+    uint32_t x = col32[(tile * 32 + r) * 2 + h];
+    for (; tile < ntiles; tile += stride) {
+        const uint64_t nt = tile + stride < ntiles ? tile + stride : tile;
+        const uint32_t xn = col32[(nt * 32 + r) * 2 + h];      // next tile's rows, in flight during this tile
+        v4i a0, a1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] = (x >> j) & 0x01010101u; a1[j] = (x >> (j + 4)) & 0x01010101u; }
+        // software pipeline over the groups: the MFMAs of group g+1 are issued before the results of group g are
+        // folded, and the B fragments of group g+2 are requested as soon as the buffer they land in has been consumed
+        v4i by0 = lbl[0], by1 = lbl[64];
+        int thrY = lt[0];
+        v4i bx0 = lbl[128], bx1 = lbl[192];
+        int thrX = lt[32];
+        v16i accY = mm(a0, a1, by0, by1), accX;
+#pragma unroll 1
+        for (int g = 0; g < GROUPS - 2; g += 2) {
+            accX = mm(a0, a1, bx0, bx1);                                  // group g + 1
+            by0 = lbl[(g + 2) * 128]; by1 = lbl[(g + 2) * 128 + 64];
+            const int thrYn = lt[(g + 2) * 32];
+            reduce(accY, thrY, g, tile);
+            thrY = thrYn;
+            accY = mm(a0, a1, by0, by1);                                  // group g + 2
+            bx0 = lbl[(g + 3) * 128]; bx1 = lbl[(g + 3) * 128 + 64];
+            const int thrXn = lt[(g + 3) * 32];
+            reduce(accX, thrX, g + 1, tile);
+            thrX = thrXn;
+        }
+        accX = mm(a0, a1, bx0, bx1);
+        reduce(accY, thrY, GROUPS - 2, tile);
+        reduce(accX, thrX, GROUPS - 1, tile);
+        x = xn;
+    }
+}
+
+int main(int argc, char** argv) {
+    const uint64_t rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 16ull << 20;
+    const uint32_t nq = argc > 2 ? atoi(argv[2]) : 1024;
+    const int tau = argc > 3 ? atoi(argv[3]) : 12;
+    const int bpc = argc > 4 ? atoi(argv[4]) : 2;
+    const uint32_t cap = 16384;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    uint64_t* col; uint64_t* dq; int* dtau; uint32_t* cnt; uint64_t* cand; unsigned long long *s1, *s2;
+    CK(hipMalloc(&col, rows * 8));
+    CK(hipMalloc(&dq, nq * 8));
+    CK(hipMalloc(&dtau, nq * 4));
+    CK(hipMalloc(&cnt, nq * 4));
+    CK(hipMalloc(&cand, (size_t)nq * cap * 8));
+    CK(hipMalloc(&s1, nq * 8));
+    CK(hipMalloc(&s2, nq * 8));
+    fill<<<cus * 8, 256>>>(col, rows, 0x1511CC00ull);
+    std::vector<uint64_t> hq(nq);
+    std::vector<int> ht(nq, tau);
+    for (uint32_t i = 0; i < nq; ++i) hq[i] = (i % 4 == 0) ? splitmix64(0x1511CC00ull + 4 * (splitmix64(77 + i) % rows)) ^ (i % 16 == 0 ? 0 : 5) : splitmix64(0xABCD0000ull + i);
+    CK(hipMemcpy(dq, hq.data(), nq * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtau, ht.data(), nq * 4, hipMemcpyHostToDevice));
+    P p{col, rows / 32 * 32, dq, dtau, cnt, cand, cap, nq};
+    if (nq != 1024 && nq != 512 && nq != 256) { printf("queries must be 256, 512 or 1024\n"); return 1; }
+    const int groups = nq / 32;
+    const size_t lds = (size_t)groups * 2 * 64 * 16 + (size_t)nq * 8;
+    auto launch = [&]() {
+        dim3 grid(cus * bpc);
+        if (groups == 32) hipLaunchKernelGGL(mfma_scan<32>, grid, dim3(256), lds, 0, p);
+        else if (groups == 16) hipLaunchKernelGGL(mfma_scan<16>, grid, dim3(256), lds, 0, p);
+        else hipLaunchKernelGGL(mfma_scan<8>, grid, dim3(256), lds, 0, p);
+    };
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipMemset(cnt, 0, nq * 4));
+    launch();
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int it = 0; it < 5; ++it) {
+        CK(hipMemset(cnt, 0, nq * 4));
+        CK(hipEventRecord(e0));
+        launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double pairs = (double)p.n_rows * nq;
+    printf("mfma_scan: rows=%llu queries=%u tau=%d blocks/CU=%d lds=%zu B : %.3f ms  %.3e pairs/s  (%.1f cycles@2.4GHz per 1024 pairs per SIMD)  %.2f PB/s int8-ops of 5.03\n",
+           (unsigned long long)p.n_rows, nq, tau, bpc, lds, best, pairs / (best * 1e-3),
+           best * 1e-3 * 2.4e9 / (pairs / 1024 / (cus * 4.0)), pairs * 128 / (best * 1e-3) / 1e15);
+    // check against brute force
+    std::vector<uint32_t> c1(nq), c2(nq);
+    std::vector<unsigned long long> h1(nq), h2(nq);
+    CK(hipMemset(s1, 0, nq * 8));
+    checksum<<<nq, 256>>>(p, s1);
+    CK(hipMemcpy(c1.data(), cnt, nq * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h1.data(), s1, nq * 8, hipMemcpyDeviceToHost));
+    CK(hipMemset(cnt, 0, nq * 4));
+    CK(hipMemset(s2, 0, nq * 8));
+    brute<<<cus * 8, 256>>>(p, s2);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(c2.data(), cnt, nq * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h2.data(), s2, nq * 8, hipMemcpyDeviceToHost));
+    uint64_t total = 0, bad = 0;
+    for (uint32_t q = 0; q < nq; ++q) {
+        total += c2[q];
+        if (c1[q] != c2[q] || (c2[q] <= cap && h1[q] != h2[q])) { if (bad < 5) printf("  MISMATCH q=%u mfma cnt=%u brute cnt=%u\n", q, c1[q], c2[q]); ++bad; }
+    }
+    printf("check: %llu hits over %u queries, %llu queries differ -> %s\n", (unsigned long long)total, nq, (unsigned long long)bad, bad ? "FAIL" : "OK");
+    return bad ? 1 : 0;
+}
