@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """
-bench.py -- queries/sec and achieved HBM GB/s of the brute-force 64-bit Hamming k=10 search.
+bench.py -- queries/sec of the exact brute-force 64-bit Hamming k=10 search, with the roofline that binds the timed kernel.
 
-Workload (BASELINE.json `metric`): 100 M synthetic 64-bit codes resident in HBM, k = 10, batches of
-1 024 queries streamed as passes of T_q (=8) queries.  A "step" is one 1 024-query search through
-the C-ABI (threshold bootstrap + sample scan + streaming scan + select [+ all-gather + merge]).
+Workload (BASELINE.json `metric`): 100 M synthetic 64-bit codes resident in HBM, k = 10, batches of 1 024 queries.
+A "step" is one 1 024-query search through the C-ABI (threshold bootstrap + levels + collect scan + select
+[+ all-gather + merge]).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`;
    one rank per GPU over RCCL; STRONG scaling: the 100 M rows are row-range sharded over the ranks,
    every rank answers every query on its shard, ONE all-gather exchanges the per-shard top-k.)
 
-Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes of the streaming-scan
-launches (rows x 8 x words x query groups) / their summed device time, measured
-with HIP events on the library's own stream inside the timed region.  `cpu_baseline` = the oracle
-(CPU restatement, OpenMP) timed on the host cores over the same 100 M rows for a bounded number of
-queries (rank 0, N = 1 only).
+Prints ONE JSON line on rank 0.
+
+`roofline` describes the dominant kernel of the TIMED steps, measured with HIP events on the library's own stream
+inside the timed region:
+  * batches of >= 64 queries run the collect scan on the int8 matrix cores (csrc/mfma_scan.hip): bound "mfma",
+    achieved = (rows x queries x 64-bit words) x 128 int8 operations / launch time, peak = dense int8 MFMA rate;
+  * with `--opt mfma=0` the XOR + popcount kernel runs: cache-blocked it is bound by VALU issue (bound "valu",
+    in (row, query, word) triples per second against the measured issue rates of v_xor / v_bcnt / v_min3), and with
+    `--opt stretch_mb=0` every pass streams from HBM (bound "hbm", algorithmic bytes / time).
+After the timed region (N = 1) the same step runs a few more times in the two other regimes, so that every default run
+also carries the HBM-roofline evidence `north_star` asks for (`roofline_streaming`) and the VALU kernel's figure
+(`roofline_valu`).
+
+`cpu_baseline` = the oracle (CPU restatement, OpenMP) timed on the host cores over the same 100 M rows (rank 0, N = 1
+only); its answers are compared bit for bit with the GPU's for the same queries (`parity_checked_queries`; a mismatch
+fails the run).  Beside it: `py_memory_style` (the reference's memory:// loop restated, one core) and `usearch`
+("unavailable": the HNSW wheels cannot be installed offline) -- SURVEY.md section 8d.
 """
 
 import argparse
@@ -33,9 +45,17 @@ if ROOT not in sys.path:
 SEED_CODES = 0x1511CC00
 SEED_Q = 0x1511CC02
 SEED_P = 0x1511CC03
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
-VALU_PEAK_TLANEOPS = 39.3  # 1024 SIMDs x 16 lanes x 2.4 GHz (profiles/r01_micro_valu.txt: 4 cycles per wave64 integer op)
 MASK64 = (1 << 64) - 1
+
+# peaks (MI355X_MICROARCH.md; profiles/r02_micro_valu2.txt for the integer VALU issue rates)
+HBM_PEAK_GBS = 8000.0                       # HBM3E spec; 6.29 TB/s is the guide's measured copy ceiling
+SIMDS, CLOCK_HZ = 1024, 2.4e9               # 256 CUs x 4 SIMDs, max clock
+MFMA_I8_PEAK_TOPS = SIMDS * 2048 * CLOCK_HZ / 1e12      # v_mfma_i32_32x32x32_i8: 32*32*32*2 ops per 32 cycles per SIMD = 5 033 TOP/s dense
+# XOR + popcount kernel, per wave64 and (row, query, word): 2 v_xor (2 cycles each with VGPR sources) + 2 v_bcnt (4 each)
+# + half a v_min3 (4) = 14 issue cycles for 64 triples
+VALU_CYCLES_PER_64_TRIPLES = 14.0
+VALU_PEAK_GTRIPLES = SIMDS * CLOCK_HZ * 64 / VALU_CYCLES_PER_64_TRIPLES / 1e9
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_fetch_size.json")
 
 
 def splitmix64(x):
@@ -63,6 +83,56 @@ def make_queries(nq, rows, words):
     return q, planted
 
 
+def roofline_of(st, args, words, regime):
+    """The roofline object of one measured leg from the engine's statistics (HIP events around every collect launch)."""
+    if not st["scan_launches"] or st["scan_ms"] <= 0:
+        return None
+    secs = st["scan_ms"] / 1e3
+    launches = st["scan_launches"]
+    out = {
+        "launches": launches,
+        "avg_launch_ms": st["scan_ms"] / launches,
+        "algorithmic_bytes_per_launch": st["scan_bytes"] / launches,       # rows x 8 x words x passes of T_q queries (SURVEY 8d)
+        "triples_per_launch": st["scan_pair_words"] / launches,            # (row, query, 64-bit word)
+        "regime": regime,
+    }
+    mfma = st["scan_mfma_launches"] == launches
+    if mfma:
+        ops = st["scan_pair_words"] * 128.0                                # 64 multiply-adds per triple
+        out.update({"bound": "mfma", "kernel": "isk::mfma_scan_kernel<W=%d> (v_mfma_i32_32x32x32_i8)" % words,
+                    "achieved": ops / secs / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8, dense)"})
+    elif regime.startswith("streaming"):
+        out.update({"bound": "hbm", "kernel": "isk::scan_adapt_kernel / scan_kernel (XOR + popcount), one pass of T_q queries per table read",
+                    "achieved": st["scan_bytes"] / 1e9 / secs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "measured_copy_ceiling_GBs": 6290.0, "measured_read_ceiling_GBs": 7050.0})
+    else:
+        out.update({"bound": "valu", "kernel": "isk::scan_adapt_kernel / scan_kernel (XOR + popcount), rows served by L2 / Infinity Cache",
+                    "achieved": st["scan_pair_words"] / 1e9 / secs, "peak": VALU_PEAK_GTRIPLES, "unit": "G (row, query, word) triples/s",
+                    "peak_derivation": "1024 SIMDs x 2.4 GHz x 64 lanes / 14 issue cycles per 64 triples (2 v_xor @ 2 + 2 v_bcnt @ 4 + 1/2 v_min3 @ 4; "
+                                       "profiles/r02_micro_valu2.txt)",
+                    "algorithmic_GBs": st["scan_bytes"] / 1e9 / secs})
+    out["frac"] = out["achieved"] / out["peak"]
+    return out
+
+
+def attach_traffic(roof, key):
+    """
+    HBM traffic of the kernel per launch, from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in a run of its own,
+    gfx950 x2 correction), scaled to this run's launch size.  Never measured inside this run: the profile names the
+    commit it was taken at and must be regenerated when the kernels change.
+    """
+    roof["traffic"] = None
+    roof["traffic_measured_in_run"] = False
+    try:
+        with open(os.path.join(ROOT, PMC_PROFILE)) as f:
+            pmc = json.load(f)
+        entry = pmc["regimes"][key]
+        roof["traffic"] = entry["corrected_bytes_per_launch"] * roof["triples_per_launch"] / entry["triples_per_launch"]
+        roof["traffic_source"] = "%s [%s], kernels at commit %s" % (PMC_PROFILE, key, pmc.get("commit", "?"))
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,11 +143,11 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nbytes", type=int, default=8, help="code length in bytes (8 = 64-bit)")
     ap.add_argument("--metric", choices=["hamming", "nphd"], default="hamming", help="table metric (nphd: every row --nbytes long, queries too)")
-    ap.add_argument("--tq", type=int, default=8, help="queries per pass (8|16); 8 keeps a streaming scan HBM-bound")
+    ap.add_argument("--tq", type=int, default=8, help="queries per pass of the XOR + popcount kernel (8|16); 8 keeps a streaming scan HBM-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed on the CPU (0 = auto, ~10-30 s)")
+    ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed (and parity-checked) on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
-    ap.add_argument("--no-streaming-check", action="store_true", help="skip the extra HBM-streaming measurement (stretch_mb=0) after the timed region")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the VALU / HBM-streaming measurements after the timed region")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0 and the process group runs over gloo "
                          "(ranks sharing a GPU cannot form an RCCL communicator); the number it prints is not a scaling result")
@@ -123,13 +193,11 @@ def main():
     words = (args.nbytes + 7) // 8
     engine = HipEngine(local_rank)
     engine.set_option("queries_per_pass", args.tq)
+    opts = {"mfma": 1, "stretch_mb": 128, "mfma_min_queries": 64}
     for kv in args.opt:
         name, _, val = kv.partition("=")
         engine.set_option(name, int(val))
-    stretch_mb = 128
-    for kv in args.opt:
-        if kv.startswith("stretch_mb="):
-            stretch_mb = int(kv.split("=")[1])
+        opts[name] = int(val)
     nphd = args.metric == "nphd"
     table = engine.open_table(_lib.METRIC_NPHD if nphd else _lib.METRIC_HAMMING, 1, args.nbytes)
     q_nbytes = np.full(args.queries, args.nbytes, dtype=np.uint8) if nphd else None
@@ -147,8 +215,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # correctness gate outside the timed region: planted neighbours must come back first
-    keys, ham, pbits, cnt = step()
+    # correctness gate outside the timed region: planted neighbours must come back first; the full answer is kept and
+    # compared with the oracle's below (cpu_baseline)
+    first = step()
+    keys, ham, pbits, cnt = first
     for j, (r, f) in planted.items():
         assert int(cnt[j]) == min(args.k, args.rows), (j, cnt[j])
         assert int(ham[j, 0]) <= f, f"planted neighbour of query {j} not found: {ham[j, :3]} vs {f}"
@@ -156,86 +226,75 @@ def main():
             assert int(keys[j, 0]) == r or int(ham[j, 0]) == 0
     assert np.all(np.diff(ham.astype(np.int64), axis=1)[:, : args.k - 1] >= 0), "results not sorted"
 
+    def measure(steps, timed):
+        """`steps` steps with per-launch HIP events; returns (seconds, statistics)."""
+        fence()
+        engine.stats(reset=True)
+        if not args.no_profile:
+            engine.set_option("profile", 1)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        el = time.perf_counter() - t0
+        engine.set_option("profile", 0)
+        st = engine.stats(reset=True)
+        if not timed:
+            for a, b in zip(out, first):
+                assert np.array_equal(a, b), "a regime returned different results"
+        return el, st
+
     for _ in range(args.warmup):
         step()
-    fence()
-    engine.stats(reset=True)
-    if not args.no_profile:
-        engine.set_option("profile", 1)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    engine.set_option("profile", 0)
-    st = engine.stats(reset=True)
+    elapsed, st = measure(args.steps, True)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # Outside the timed region, rank 0 of a one-GPU run: the same steps with cache blocking OFF, i.e. every query
-    # group streams the table from HBM -- the measurement that evidences the HBM roofline of the scan kernel
-    # (with blocking on, all but the first group of a launch read their stretch from the 256 MB Infinity Cache).
-    streaming = None
-    if world == 1 and not args.no_profile and not args.no_streaming_check:
-        engine.set_option("stretch_mb", 0)
-        step()
-        torch.cuda.synchronize()
-        engine.stats(reset=True)
-        engine.set_option("profile", 1)
-        t1 = time.perf_counter()
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
-        engine.set_option("profile", 0)
-        s2 = engine.stats(reset=True)
-        if s2["scan_ms"] > 0:
-            a2 = (s2["scan_bytes"] / 1e9) / (s2["scan_ms"] / 1e3)
-            streaming = {
-                "what": "same workload with stretch_mb=0 (no cache blocking): every pass streams the rows from HBM",
-                "bound": "hbm", "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,
-                "launches": s2["scan_launches"], "avg_launch_ms": s2["scan_ms"] / s2["scan_launches"],
-                "algorithmic_bytes_per_launch": s2["scan_bytes"] / s2["scan_launches"],
-                "queries_per_s": args.queries * 5 / el,
-            }
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size_scan_tq8.json")) as f:
-                    per_row = json.load(f)["corrected_bytes_per_row_pass_streaming"]
-                if args.nbytes == 8 and args.tq == 8:
-                    streaming["traffic"] = per_row * streaming["algorithmic_bytes_per_launch"] / 8.0
-            except (OSError, KeyError, ValueError):
-                pass
+    batched = args.queries > args.tq
+    mfma_on = opts["mfma"] and args.queries >= opts["mfma_min_queries"]
 
-    # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected x2
-    # for gfx950's half-count of 16 B/lane streams): bytes per pass for this workload, scaled to one launch.
-    traffic = None
-    traffic_src = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size_scan_tq8.json")) as f:
-            pmc = json.load(f)
-        per_row = None
-        if args.nbytes == 8 and args.tq == 8 and world == 1:
-            if stretch_mb == 0 or args.queries <= args.tq:
-                per_row = pmc["corrected_bytes_per_row_pass_streaming"]
-            elif stretch_mb == 128 and args.queries == 1024:
-                per_row = pmc["corrected_bytes_per_row_pass"]
-        if per_row and st["scan_launches"]:
-            # bytes the L2s fetched per (row, query group) of the collect scan, scaled to one launch of this run
-            traffic = per_row * (st["scan_bytes"] / 8.0) / st["scan_launches"]
-            traffic_src = ("profiles/r01_pmc_fetch_size_scan_tq8.json (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; "
-                           "FETCH_SIZE counts L2 misses, Infinity-Cache hits included)")
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    def regime_name(mfma, stretch_mb):
+        if mfma:
+            return "matrix cores: each block keeps up to %d expanded queries in LDS, the rows cross the memory system once per chunk" % (1024 // words)
+        if stretch_mb and batched:
+            return ("cache-blocked: all query groups of a launch share stretches of <= %d MB, read from HBM once and from the 256 MB Infinity "
+                    "Cache afterwards" % stretch_mb)
+        return "streaming: every pass of T_q queries reads the rows from HBM"
+
+    roof = roofline_of(st, args, words, regime_name(mfma_on, opts["stretch_mb"])) if not args.no_profile else None
+    if roof:
+        attach_traffic(roof, "mfma" if mfma_on else ("valu_blocked" if opts["stretch_mb"] and batched else "valu_streaming"))
+
+    # Outside the timed region (one GPU): the same step in the other regimes.
+    extra = {}
+    if world == 1 and not args.no_profile and not args.no_extra_legs and batched:
+        legs = []
+        if mfma_on:
+            legs.append(("roofline_valu", {"mfma": 0, "stretch_mb": opts["stretch_mb"] or 128}))
+        if mfma_on or opts["stretch_mb"]:
+            legs.append(("roofline_streaming", {"mfma": 0, "stretch_mb": 0}))
+        for name, o in legs:
+            for k_, v_ in o.items():
+                engine.set_option(k_, v_)
+            step()
+            el, s2 = measure(5, False)
+            r2 = roofline_of(s2, args, words, regime_name(False, o["stretch_mb"]))
+            if r2:
+                r2["queries_per_s"] = args.queries * 5 / el
+                r2["what"] = "same workload, outside the timed region, engine options %s" % o
+                attach_traffic(r2, "valu_blocked" if o["stretch_mb"] else "valu_streaming")
+                extra[name] = r2
+        engine.set_option("mfma", opts["mfma"])
+        engine.set_option("stretch_mb", opts["stretch_mb"])
 
     total_queries = args.queries * args.steps
     qps = total_queries / elapsed
-    achieved = (st["scan_bytes"] / 1e9) / (st["scan_ms"] / 1e3) if st["scan_ms"] > 0 else None
     out = {
-        "metric": "queries/sec (+ achieved HBM GB/s in `roofline`), 64-bit Hamming k=10 over 100M codes, exact top-k",
+        "metric": "queries/sec (+ roofline of the dominant kernel), 64-bit Hamming k=10 over 100M codes, exact top-k",
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
@@ -245,55 +304,31 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u64",
+        "dtype": "i8 (0/1 x +-1 products accumulated in i32)" if mfma_on else "u64",
         "data": "synthetic",
         "config": {
             "workload": f"{args.rows} x {args.nbytes * 8}-bit codes, brute-force {'NPHD' if nphd else 'Hamming'} k={args.k}, "
-                        f"{args.queries} queries/step in passes of T_q={args.tq}, rows sharded over {world} GPU(s)",
+                        f"{args.queries} queries/step, rows sharded over {world} GPU(s)",
             "rows_total": args.rows,
             "rows_per_gpu": hi - lo,
             "code_bits": args.nbytes * 8,
             "k": args.k,
             "queries_per_step": args.queries,
             "queries_per_pass": args.tq,
+            "scan": "int8 MFMA" if mfma_on else "XOR + popcount",
             "parallelism": f"row-shard x{world}, one all-gather of per-shard top-k",
         },
-        "roofline": {
-            "bound": "hbm",
-            # the collect pass: scan_adapt_kernel<T_q, 3> for whole 64-bit codes, scan_kernel<W, mask, T_q, 3> otherwise
-            # (mode 3 = MODE_STRETCH; the threshold levels in front of it are mode 2 launches of the same code)
-            "kernel": ("scan_adapt_kernel<%d,STRETCH>" % args.tq) if words == 1 and args.nbytes % 8 == 0 else "scan_kernel<W=%d,STRETCH>" % words,
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "launches": st["scan_launches"],
-            "avg_launch_ms": (st["scan_ms"] / st["scan_launches"]) if st["scan_launches"] else None,
-            "algorithmic_bytes_per_launch": (st["scan_bytes"] / st["scan_launches"]) if st["scan_launches"] else None,
-            "regime": ("cache-blocked: %d query groups per launch share stretches of <= %d MB, read from HBM once and from the "
-                       "256 MB Infinity Cache afterwards, so the algorithmic rate may exceed what HBM alone delivers; the kernel "
-                       "is then bound by integer VALU issue (see `valu`); `roofline_streaming` is the HBM-bound measurement"
-                       % (st["scan_passes"] // max(1, st["scan_launches"]), stretch_mb)) if stretch_mb and args.queries > args.tq else "streaming",
-            "measured_copy_ceiling_GBs": 6290.0,          # MI355X_MICROARCH.md: measured streaming copy
-            "measured_read_ceiling_GBs": 7050.0,          # profiles/r01_micro_read.txt: pure nontemporal read, same device
-        },
+        "roofline": roof,
         # every row is read exactly once per pass: the threshold levels (sample_bytes) stream the first stretch of
         # the table, the collect scan (scan_bytes) the rest
-        "whole_step_GBs": ((st["scan_bytes"] + st["sample_bytes"]) / 1e9) / elapsed,
+        "whole_step_algorithmic_GBs": ((st["scan_bytes"] + st["sample_bytes"]) / 1e9) / elapsed,
         "fallback_queries": st["fallback_queries"],
     }
-    if achieved:
-        # 4.5 VALU lane-operations per (row, query, 64-bit word): the other roofline of this kernel
-        lane_ops = achieved * 1e9 / 8.0 * args.tq * 4.5
-        out["roofline"]["valu"] = {"achieved": lane_ops / 1e12, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
-                                   "frac": lane_ops / 1e12 / VALU_PEAK_TLANEOPS}
-    if streaming:
-        out["roofline_streaming"] = streaming
+    out.update(extra)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, q, words)
+        out["cpu_baseline"] = cpu_baseline(args, q, words, first)
+        out["parity_checked_queries"] = out["cpu_baseline"]["parity_checked_queries"]
 
     if rank == 0:
         print(json.dumps(out))
@@ -320,8 +355,30 @@ def usable_cores(omp_threads):
     return max(1, n)
 
 
-def cpu_baseline(args, q, words):
-    """The oracle (CPU restatement of the same exact search) on the host cores, bounded to ~10-30 s."""
+def py_memory_style(n_assets=2500, n_queries=200):
+    """
+    SURVEY.md section 8d-ii: what the reference's memory:// backend does per search (iscc_search/indexes/memory/index.py:204-232),
+    restated: normalise the query, compare the iscc_code STRING with every stored asset, score 1.0.  No distance is
+    computed; one core, GIL-bound by construction.  Config 1's shape: 2 500 assets x 4 units = 10 000 64-bit units.
+    """
+    import base64
+
+    rng = np.random.default_rng(0)
+    codes = ["ISCC:" + base64.b32encode(rng.integers(0, 256, size=34, dtype=np.uint8).tobytes()).decode().rstrip("=") for _ in range(n_assets)]
+    store = {i: {"iscc_id": i, "iscc_code": c, "units": [c[:21]] * 4, "metadata": None} for i, c in enumerate(codes)}
+    t0 = time.perf_counter()
+    for j in range(n_queries):
+        code = codes[j]
+        types = {u: 1.0 for u in store[j]["units"]}
+        hits = [(a["iscc_id"], 1.0, types, a["metadata"]) for a in store.values() if code and a["iscc_code"] and a["iscc_code"] == code][:10]
+        assert len(hits) == 1
+    dt = time.perf_counter() - t0
+    return {"value": n_queries / dt, "unit": "searches/s", "cores": 1, "kind": "port",
+            "sample": f"{n_queries} iscc_code equality searches over {n_assets} assets (config 1: 10 000 units); no distance computed"}
+
+
+def cpu_baseline(args, q, words, gpu):
+    """The oracle (CPU restatement of the same exact search) on the host cores, bounded to ~10-30 s; its answers check the GPU's."""
     from oracle import oracle_num_threads, oracle_splitmix64_fill, oracle_topk
 
     rows = args.rows
@@ -331,36 +388,53 @@ def cpu_baseline(args, q, words):
         code_words[:, -1] &= np.uint64((MASK64 << (8 * (8 - args.nbytes % 8))) & MASK64)
     keys = np.arange(rows, dtype=np.uint64)
     threads = usable_cores(oracle_num_threads())
+    nphd = args.metric == "nphd"
+    lens = np.full(rows, args.nbytes, dtype=np.uint8) if nphd else None
+
+    def run(qs, nthreads):
+        qn = np.full(len(qs), args.nbytes, dtype=np.uint8) if nphd else None
+        return oracle_topk(1 if nphd else 0, keys, code_words, lens, qs, qn, args.k, fixed_nbytes=0 if nphd else args.nbytes, threads=nthreads)
+
     nq = args.cpu_queries
     if nq <= 0:
-        # calibrate on 2 queries, then size the sample for ~15 s
+        # calibrate on 8 queries, then size the sample for ~15 s
         t0 = time.perf_counter()
-        oracle_topk(0, keys, code_words, None, q[:8], None, args.k, fixed_nbytes=args.nbytes, threads=threads)
+        run(q[:8], threads)
         per_q = (time.perf_counter() - t0) / 8
         nq = int(max(8, min(args.queries, 15.0 / max(per_q, 1e-6))))
+    nq = min(nq, args.queries)
     reps = 1
     if args.cpu_queries <= 0 and nq == args.queries:
         reps = int(max(1, min(16, round(12.0 / max(per_q * nq, 1e-6)))))    # ~12 s of CPU work
     t0 = time.perf_counter()
     for _ in range(reps):
-        oracle_topk(0, keys, code_words, None, q[:nq], None, args.k, fixed_nbytes=args.nbytes, threads=threads)
+        exp = run(q[:nq], threads)
     dt = time.perf_counter() - t0
-    nq = nq * reps
+    # parity: the oracle's answers for those queries against what the GPU returned for them before the timed region
+    for name, g, e in zip(("keys", "hamming", "prefix_bits", "count"), gpu, exp):
+        if not np.array_equal(g[:nq], e):
+            bad = int(np.nonzero(np.any((g[:nq] != e).reshape(nq, -1), axis=1))[0][0])
+            raise SystemExit(f"PARITY FAILURE: GPU {name} differ from the oracle for query {bad}: {g[bad]} vs {e[bad]}")
     # one core, on a 10 M-row slice (scaled linearly to the full table; labelled as extrapolated)
     slice_rows = min(rows, 10_000_000)
     t1 = time.perf_counter()
-    oracle_topk(0, keys[:slice_rows], code_words[:slice_rows], None, q[:4], None, args.k, fixed_nbytes=args.nbytes, threads=1)
+    oracle_topk(1 if nphd else 0, keys[:slice_rows], code_words[:slice_rows], None if lens is None else lens[:slice_rows], q[:4],
+                np.full(4, args.nbytes, dtype=np.uint8) if nphd else None, args.k, fixed_nbytes=0 if nphd else args.nbytes, threads=1)
     dt1 = time.perf_counter() - t1
     return {
         "single_core": {"value": 4 / dt1 * slice_rows / rows, "unit": "queries/s", "cores": 1,
                         "sample": f"4 queries over a {slice_rows}-row slice, extrapolated linearly to {rows} rows"},
-        "value": nq / dt,
+        "value": nq * reps / dt,
         "unit": "queries/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{nq} queries ({reps} x the step's batch) over all {rows} rows ({dt:.1f} s of CPU work, {threads} OpenMP threads = "
+        "sample": f"{nq * reps} queries ({reps} x {nq} of the step's batch) over all {rows} rows ({dt:.1f} s of CPU work, {threads} OpenMP threads = "
                   f"the CPUs this process may use; rows split across threads, cache-blocked over all queries)",
-        "GBs": nq * rows * 8 * words / dt / 1e9,
+        "GBs": nq * reps * rows * 8 * words / dt / 1e9,
+        "parity_checked_queries": nq,
+        "parity": f"keys, hamming, prefix_bits and counts of the GPU's answer to the first {nq} queries of the step are bit-identical to the oracle's",
+        "py_memory_style": py_memory_style(),
+        "usearch": "unavailable (iscc-usearch 0.8.1 / usearch-iscc 2.24.6 wheels are not in the image and cannot be installed offline; not estimated)",
     }
 
 

@@ -48,6 +48,10 @@ class Stats(ctypes.Structure):
         ("queries_per_pass", ctypes.c_uint32),
         ("compute_units", ctypes.c_uint32),
         ("freq_builds", ctypes.c_uint64),
+        ("mfma_launches", ctypes.c_uint64),
+        ("mfma_pair_words", ctypes.c_uint64),
+        ("scan_pair_words", ctypes.c_uint64),
+        ("scan_mfma_launches", ctypes.c_uint64),
     ]
 
     def as_dict(self):

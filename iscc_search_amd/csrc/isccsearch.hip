@@ -30,6 +30,7 @@
 
 #include "../../include/isccsearch.h"
 #include "kernels.hip.h"
+#include "mfma_scan.h"
 #include "docfreq.h"
 #include "keymap.h"
 
@@ -156,6 +157,10 @@ struct isccsearch_handle {
     bool repick = true;            // re-derive the threshold after every collect stretch but the last
     uint32_t fold_tau = 11;        // 64-bit codes: groups whose thresholds are all <= this take the folded fast path (0: off)
     uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
+    // large batches: the scan as an int8 matrix-core contraction (mfma_scan.hip) instead of XOR + popcount on the VALU
+    bool mfma = true;
+    uint32_t mfma_min_queries = 64;   // batches below this stay on the VALU kernel (HBM-bound up to ~11 queries per pass)
+    uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
     // scratch
@@ -400,7 +405,7 @@ struct Batch {
         Ctx c{};
         for (uint32_t w = 0; w < j.W; ++w) c.sp.col[w] = s.col[w];
         c.sp.queries = h->d_queries.p; c.sp.bias = h->d_bias.p; c.sp.cnt = h->d_cnt.p; c.sp.cand = h->d_cand.p;
-        c.sp.ghist = h->d_ghist.p; c.sp.cap = cap; c.sp.k = k; c.sp.fold_tau = h->fold_tau;
+        c.sp.ghist = h->d_ghist.p; c.sp.cap = cap; c.sp.k = k; c.sp.fold_tau = h->fold_tau; c.sp.nq_pad = nq_pad;
         c.sp.mask_lo = (uint32_t)j.mask_last; c.sp.mask_hi = (uint32_t)(j.mask_last >> 32);
         c.sl.cnt = h->d_cnt.p; c.sl.cand = h->d_cand.p; c.sl.cap = cap; c.sl.keys = s.keys;
         c.sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
@@ -415,6 +420,28 @@ struct Batch {
         else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
     }
     size_t flag_words() const { return jobs.size() * (size_t)nq_pad; }
+
+    // One scan launch over rows [sp.row_begin, sp.n_rows) for all query groups.  Large batches over enough rows go to
+    // the matrix cores (mfma_scan.hip): every block keeps a chunk of up to 1 024 / W expanded queries in LDS and the
+    // rows cross the memory system once per chunk; small batches stay on the XOR + popcount kernel, which is
+    // HBM-bound up to ~11 queries per pass.  Both append the same candidates under the same thresholds.
+    bool use_mfma(uint64_t rows) const { return h->mfma && nq_pad >= h->mfma_min_queries && rows >= h->mfma_min_rows; }
+    int scan(const Job& j, const isk::ScanParams& sp, int mode, bool sample) {
+        const uint64_t rows = sp.n_rows - sp.row_begin;
+        if (use_mfma(rows)) {
+            const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad);
+            const uint32_t chunks = (nq_pad + g * 32 - 1) / (g * 32);
+            const uint64_t steps = (rows + 63) / 64;
+            const uint64_t bx = std::max<uint64_t>(1, std::min<uint64_t>((steps + 3) / 4, std::max<uint32_t>(1, (uint32_t)h->cus * 2 / chunks)));
+            const int e = isk::launch_mfma_scan((int)j.W, mode, (uint32_t)bx, g, h->stream, sp);
+            if (e) return fail(-EIO, "mfma scan: hipFuncSetAttribute failed: %s", hipGetErrorString((hipError_t)e));
+            h->stats.mfma_launches += 1;
+            h->stats.mfma_pair_words += rows * (uint64_t)nq * j.W;
+            return 0;
+        }
+        launch_scan((int)j.W, j.mask, tq, mode, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups, sample), groups), h->stream, sp);
+        return 0;
+    }
 
     // hq: host query words [nq][max_words]
     int begin(const uint64_t* hq) {
@@ -476,14 +503,16 @@ struct Batch {
             bool hist_live = false;
             auto collect_from = [&](uint64_t from) -> int {
                 uint64_t stretch = s.n;
-                if (groups > 1 && h->stretch_bytes) stretch = std::max<uint64_t>(tile_rows, h->stretch_bytes / (8 * j.W) / tile_rows * tile_rows);
+                // (the MFMA kernel reads the rows once per CHUNK of up to 1 024 / W queries: one chunk has nothing to share)
+                const bool shared = use_mfma(s.n - from) ? nq_pad > isk::mfma_groups_per_chunk((int)j.W, nq_pad) * 32 : groups > 1;
+                if (shared && h->stretch_bytes) stretch = std::max<uint64_t>(tile_rows, h->stretch_bytes / (8 * j.W) / tile_rows * tile_rows);
                 for (uint64_t a = from; a < s.n;) {
                     const uint64_t b = s.n - a <= stretch + stretch / 4 ? s.n : a + stretch;     // no sliver at the end
                     sp.row_begin = a;
                     sp.n_rows = b;
                     const uint64_t rows = b - a;
                     hipEvent_t e0 = nullptr, e1 = nullptr;
-                    int rcl;
+                    int rcl = 0;
                     if (h->profile) { if ((rcl = event_pair(h, e0, e1))) return rcl; HIPOK(hipEventRecord(e0, h->stream)); }
                     // every stretch but the last keeps the histogram and is followed by a pick, so the threshold keeps
                     // tightening through the pass (free for k = 10, +2.5 % for k = 100; it is also what lets the
@@ -494,9 +523,9 @@ struct Batch {
                     const bool repick = hist_too && b < s.n;
                     if (hist_too) {
                         if (!hist_live) { HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream)); hist_live = true; }
-                        launch_scan((int)j.W, j.mask, tq, isk::MODE_STRETCH, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                        if ((rcl = scan(j, sp, isk::MODE_STRETCH, false))) return rcl;
                     } else {
-                        launch_scan((int)j.W, j.mask, tq, isk::MODE_COLLECT, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups), groups), h->stream, sp);
+                        if ((rcl = scan(j, sp, isk::MODE_COLLECT, false))) return rcl;
                     }
                     if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
                     if (repick) {
@@ -506,6 +535,8 @@ struct Batch {
                     h->stats.scan_launches += 1;
                     h->stats.scan_passes += groups;
                     h->stats.scan_bytes += rows * 8 * j.W * groups;
+                    h->stats.scan_pair_words += rows * (uint64_t)nq * j.W;
+                    if (use_mfma(rows)) h->stats.scan_mfma_launches += 1;
                     a = b;
                 }
                 return 0;
@@ -553,8 +584,7 @@ struct Batch {
                 }
                 sp.row_begin = done;
                 sp.n_rows = end;
-                launch_scan((int)j.W, j.mask, tq, isk::MODE_BOTH, h->nontemporal,
-                            dim3(scan_grid_x(h, j.W, end - done, groups, true), groups), h->stream, sp);
+                if ((rc = scan(j, sp, isk::MODE_BOTH, true))) return rc;
                 isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, end), h->d_cnt.p, h->d_cand.p, cap};
                 hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
                 h->stats.sample_bytes += (end - done) * 8 * j.W * groups;
@@ -818,6 +848,9 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "repick")) { h->repick = value != 0; return 0; }
     if (!strcmp(name, "fold_tau")) { if (value < 0 || value > 32) return fail(-EINVAL, "fold_tau must be 0..32"); h->fold_tau = (uint32_t)value; return 0; }
     if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
+    if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
+    if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
+    if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
     return fail(-EINVAL, "unknown option '%s'", name);
 }

@@ -33,20 +33,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace isk {
+#include "scan_params.hip.h"
 
-constexpr int BLOCK = 256;            // threads per workgroup = 4 waves of 64
-constexpr uint32_t HB = 264;          // histogram stride per query (bins 0..256 used)
-constexpr uint32_t NBINS = 257;       // hamming distance 0..256
-constexpr uint32_t CNT_STRIDE = 32;   // one candidate counter per 128-byte line: device-scope atomics on
-                                      // words of one line serialise at the memory side (~90 M/s per line)
-constexpr uint32_t BIT31 = 0x80000000u;
-constexpr uint32_t BIAS_NEVER = 0x80000000u;  // bias + h always has bit 31 set: never a candidate
-constexpr int MODE_COLLECT = 0;   // append candidates
-constexpr int MODE_HIST = 1;      // count candidates per hamming distance
-constexpr int MODE_BOTH = 2;      // both: the threshold levels
-constexpr int MODE_STRETCH = 3;   // as MODE_BOTH, for the stretches of the collect pass: a separate instantiation so that
-                                  // profilers tell the pass from the levels by kernel name
+namespace isk {
 
 struct Record {            // == isccsearch_record (24 bytes)
     uint64_t key_hi;
@@ -61,11 +50,10 @@ static_assert(sizeof(Record) == 24, "record layout");
 template <int W> struct TileCfg { static constexpr int U = (W == 1) ? 4 : (W == 2 ? 2 : 1); };
 template <int W> constexpr int tile_rows() { return BLOCK * 2 * TileCfg<W>::U; }
 // Where the TQ queries of a group live while a block scans.
-//   SGPRs (scalar operands of v_xor, nothing to load in the loop) as long as they FIT: TQ*W*2 query dwords + TQ
-//   biases + the loop's own scalars must stay under ~100 registers, beyond that hipcc spills them into VGPR lanes
-//   and every use costs a v_readlane -- a VALU instruction, the very resource the kernel is short of (W=4, TQ=8:
-//   52 spilled SGPRs = +19 % VALU work per tile; TQ=16: 211).
+//   VGPRs (every lane holds the same TQ*W*2 query dwords) as long as they fit beside the two tiles in flight: up to 32
+//   registers.  Round 1 kept them in SGPRs; an SGPR source halves the issue rate of v_xor (see vgpr() above).
 //   LDS otherwise: one broadcast ds_read_b128 per four query dwords per tile, on the LDS pipe, into VGPR operands.
+//   The thresholds (bias) stay in SGPRs: they feed v_bcnt's accumulator input, a 4-cycle op either way.
 template <int W, int TQ> constexpr bool queries_in_lds() { return TQ * W >= 24; }
 template <int W> constexpr int query_vecs() { return (2 * W + 3) / 4; }   // u32x4 slots per query in LDS
 // tiles in flight ahead of the one being scored (experiment switch; 1 = double buffering)
@@ -73,21 +61,6 @@ template <int W> constexpr int query_vecs() { return (2 * W + 3) / 4; }   // u32
 #define ISK_PREFETCH_DEPTH_W1 1
 #endif
 template <int W> constexpr int prefetch_depth() { return W == 1 ? ISK_PREFETCH_DEPTH_W1 : 1; }
-
-struct ScanParams {
-    const uint64_t* col[4];   // segment columns (word-major)
-    uint64_t row_begin;       // first row scanned (a multiple of the tile size)
-    uint64_t n_rows;          // rows [row_begin, n_rows) are scanned
-    const uint64_t* queries;  // [nq_pad][4] big-endian packed query words
-    const uint32_t* bias;     // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries)
-    uint32_t* cnt;            // [nq_pad * CNT_STRIDE] candidates appended so far (MODE_COLLECT)
-    uint64_t* cand;           // [nq_pad][cap] (hamming << 48) | row          (MODE_COLLECT)
-    uint32_t* ghist;          // [nq_pad][HB] histogram of hamming <= tau     (MODE_HIST)
-    uint32_t cap;
-    uint32_t mask_lo, mask_hi;  // mask of the last compared word (partial-word prefixes)
-    uint32_t k;                 // results wanted per query
-    uint32_t fold_tau;          // scan_adapt_kernel: groups whose thresholds are all <= this take the folded fast path (0: never)
-};
 
 __device__ __forceinline__ uint32_t bcnt(uint32_t x, uint32_t acc) {
     return (uint32_t)__builtin_popcount(x) + acc;   // cold paths: let the compiler pick the form
@@ -102,6 +75,11 @@ __device__ __forceinline__ uint32_t bcnt_s(uint32_t x, uint32_t acc_sgpr) { retu
 __device__ __forceinline__ uint32_t bcnt_v(uint32_t x, uint32_t acc) { return (uint32_t)__builtin_popcount(x) + acc; }
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return pin(min(min(a, b), c)); }
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// A wave-uniform value kept in a VGPR on purpose.  gfx950 issues the plain two-operand integer ops (v_xor, v_and, v_add,
+// shifts, v_mov) of a wave64 in 2 cycles when their sources are VGPRs, inline constants or literals, and in 4 when one
+// source is an SGPR (profiles/r02_micro_valu2.txt: v_xor_b32 v,v,v 2.47 cycles, v_xor_b32 v,s,v 4.09); v_bcnt, v_min3
+// and the other VOP3 integer ops take 4 either way.  So the query words the row words are XORed with live in VGPRs.
+__device__ __forceinline__ uint32_t vgpr(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte global load: .x/.y = row r (lo, hi), .z/.w = row r+1
 
@@ -181,18 +159,6 @@ __device__ __forceinline__ void wait_tile(u32x4 (&v)[U][W]) {
         for (int w = 0; w < W; ++w) asm volatile("" : "+v"(v[u][w]));
 }
 
-// returns the candidate's slot in the query's list (0 in MODE_HIST)
-template <int MODE>
-__device__ __forceinline__ uint32_t emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
-    uint32_t slot = 0;
-    if constexpr (MODE == MODE_COLLECT || MODE == MODE_BOTH || MODE == MODE_STRETCH) {
-        slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
-        if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)h << 48) | row;
-    }
-    if constexpr (MODE == MODE_HIST || MODE == MODE_BOTH || MODE == MODE_STRETCH) atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
-    return slot;
-}
-
 // ---------------------------------------------------------------------------------------------
 // scan_kernel<W, MASK, TQ, MODE, NT>
 //   grid = (blocks_x, query_groups); block = 256.  Group g holds queries [g*TQ, (g+1)*TQ).
@@ -224,8 +190,8 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const uint64_t v = p.queries[(uint64_t)(q0 + q) * 4 + w];
-                qlo[q][w] = sgpr((uint32_t)v);
-                qhi[q][w] = sgpr((uint32_t)(v >> 32));
+                qlo[q][w] = vgpr((uint32_t)v);
+                qhi[q][w] = vgpr((uint32_t)(v >> 32));
             }
         }
     }

@@ -1,0 +1,21 @@
+// mfma_scan.h -- host interface of mfma_scan.hip (the int8 matrix-core form of the collect scan).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "scan_params.hip.h"
+
+namespace isk {
+
+constexpr int MFMA_MAX_LDS = 80 * 1024;   // dynamic LDS ceiling requested for the kernels: two blocks per CU (160 KB)
+
+// query groups (32 queries each, an even number) one block keeps in LDS for W compared words
+uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad);
+size_t mfma_lds_bytes(int W, uint32_t groups);
+// grid = (blocks_x, chunks of groups * 32 queries); returns 0 or a hipError_t from the attribute call (check
+// hipGetLastError() for the launch itself, as with every other kernel)
+int launch_mfma_scan(int W, int mode, uint32_t blocks_x, uint32_t groups, hipStream_t st, const ScanParams& p);
+
+}  // namespace isk

@@ -1,0 +1,51 @@
+// scan_params.hip.h -- what the scan kernels of kernels.hip.h (XOR + popcount on the VALU) and of mfma_scan.hip (int8
+// matrix cores) share: constants, the launch parameters and the candidate append.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace isk {
+
+constexpr int BLOCK = 256;            // threads per workgroup = 4 waves of 64
+constexpr uint32_t HB = 264;          // histogram stride per query (bins 0..256 used)
+constexpr uint32_t NBINS = 257;       // hamming distance 0..256
+constexpr uint32_t CNT_STRIDE = 32;   // one candidate counter per 128-byte line: device-scope atomics on
+                                      // words of one line serialise at the memory side (~90 M/s per line)
+constexpr uint32_t BIT31 = 0x80000000u;
+constexpr uint32_t BIAS_NEVER = 0x80000000u;  // bias + h always has bit 31 set: never a candidate
+constexpr int MODE_COLLECT = 0;   // append candidates
+constexpr int MODE_HIST = 1;      // count candidates per hamming distance
+constexpr int MODE_BOTH = 2;      // both: the threshold levels
+constexpr int MODE_STRETCH = 3;   // as MODE_BOTH, for the stretches of the collect pass: a separate instantiation so that
+                                  // profilers tell the pass from the levels by kernel name
+
+struct ScanParams {
+    const uint64_t* col[4];   // segment columns (word-major)
+    uint64_t row_begin;       // first row scanned (a multiple of the tile size)
+    uint64_t n_rows;          // rows [row_begin, n_rows) are scanned
+    const uint64_t* queries;  // [nq_pad][4] big-endian packed query words
+    const uint32_t* bias;     // [nq_pad] 0x7FFFFFFF - tau  (BIAS_NEVER for padding queries)
+    uint32_t* cnt;            // [nq_pad * CNT_STRIDE] candidates appended so far (MODE_COLLECT)
+    uint64_t* cand;           // [nq_pad][cap] (hamming << 48) | row          (MODE_COLLECT)
+    uint32_t* ghist;          // [nq_pad][HB] histogram of hamming <= tau     (MODE_HIST)
+    uint32_t cap;
+    uint32_t mask_lo, mask_hi;  // mask of the last compared word (partial-word prefixes)
+    uint32_t k;                 // results wanted per query
+    uint32_t fold_tau;          // scan_adapt_kernel: groups whose thresholds are all <= this take the folded fast path (0: never)
+    uint32_t nq_pad;            // queries (bias entries) behind `queries` / `bias`: the MFMA kernel pads its last chunk itself
+};
+
+// returns the candidate's slot in the query's list (0 in MODE_HIST)
+template <int MODE>
+__device__ __forceinline__ uint32_t emit(const ScanParams& p, uint32_t qi, uint32_t h, uint64_t row) {
+    uint32_t slot = 0;
+    if constexpr (MODE == MODE_COLLECT || MODE == MODE_BOTH || MODE == MODE_STRETCH) {
+        slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
+        if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)h << 48) | row;
+    }
+    if constexpr (MODE == MODE_HIST || MODE == MODE_BOTH || MODE == MODE_STRETCH) atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
+    return slot;
+}
+
+}  // namespace isk

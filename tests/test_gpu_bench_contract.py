@@ -31,15 +31,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert out["unit"] == "queries/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert abs(out["value"] - 1024 / (out["ms_per_step"] / 1e3)) / out["value"] < 1e-6
+    assert out["config"]["scan"] == "int8 MFMA"
     assert "workload" in out["config"] and "model" not in out["config"]
     roof = out["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_run"):
         assert key in roof, key
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # 1 024-query steps run on the matrix cores by default; whatever the bound, the fraction is a fraction
+    assert roof["bound"] == "mfma" and roof["unit"].startswith("TOP/s") and abs(roof["peak"] - 5033.2) < 1.0
+    assert roof["traffic_measured_in_run"] is False
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] <= 1.0
     assert roof["launches"] >= 3 and roof["avg_launch_ms"] > 0
+    # the two other regimes of the same step, measured outside the timed region
+    valu, stream = out["roofline_valu"], out["roofline_streaming"]
+    assert valu["bound"] == "valu" and 0 < valu["frac"] <= 1.0
+    assert stream["bound"] == "hbm" and stream["unit"] == "GB/s" and stream["peak"] == 8000.0 and 0 < stream["frac"] <= 1.0
     cpu = out["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "py_memory_style", "usearch"):
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0
-    assert out["roofline_streaming"]["bound"] == "hbm" and out["roofline_streaming"]["achieved"] > 0
+    assert cpu["py_memory_style"]["value"] > 0 and cpu["usearch"].startswith("unavailable")
+    # the oracle's answers of the CPU leg were compared bit for bit with the GPU's
+    assert out["parity_checked_queries"] == 64

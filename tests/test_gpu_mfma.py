@@ -1,0 +1,118 @@
+"""
+The int8 matrix-core form of the scan (``csrc/mfma_scan.hip``) against the oracle.
+
+By default the engine sends a launch to the matrix cores only for batches of >= 64 queries over >= 65 536 rows, which
+most parity cases are too small to reach.  Here the thresholds are dropped to 1 query / 1 row so that EVERY scan launch
+of the re-run parity, range-limited, fuzz and search_many cases takes that path (all code lengths 1..32 bytes, masked
+prefixes, mixed-length NPHD segments, 64- and 128-bit keys, tails that are not a multiple of 64 rows, overflow
+fallback), and a large-batch case runs under the default thresholds.
+"""
+
+import numpy as np
+import pytest
+
+import test_gpu_fuzz as fuzz
+import test_gpu_many as many
+import test_gpu_parity as parity
+import test_gpu_within as within
+from oracle import oracle_topk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def forced(hip_engine):
+    """Every scan launch on the matrix cores; restored afterwards."""
+    hip_engine.set_option("mfma", 1)
+    hip_engine.set_option("mfma_min_queries", 1)
+    hip_engine.set_option("mfma_min_rows", 1)
+    before = hip_engine.stats()["mfma_launches"]
+    yield hip_engine
+    ran = hip_engine.stats()["mfma_launches"] - before
+    hip_engine.set_option("mfma_min_queries", 64)
+    hip_engine.set_option("mfma_min_rows", 65536)
+    assert ran > 0, "the case never reached the MFMA kernel"
+
+
+@pytest.mark.parametrize("n,k,nq", [(100, 10, 5), (5000, 10, 33), (70000, 10, 40), (300000, 100, 17), (200001, 10, 300)])
+def test_hamming64_random(forced, n, k, nq):
+    parity.test_hamming64_random_vs_oracle(forced, n, k, nq)
+
+
+def test_hamming64_heavy_ties(forced):
+    parity.test_hamming64_heavy_ties(forced)
+
+
+@pytest.mark.parametrize("key_words", [1, 2])
+def test_identical_codes_overflow_fallback(forced, key_words):
+    parity.test_all_identical_codes_take_the_exact_fallback(forced, key_words)
+
+
+@pytest.mark.parametrize("nbytes", [1, 4, 8, 16, 24, 32, 13])
+def test_fixed_lengths_128bit_keys(forced, nbytes):
+    parity.test_hamming_fixed_lengths_128bit_keys(forced, nbytes)
+
+
+def test_nphd_mixed_lengths(forced):
+    parity.test_nphd_mixed_lengths_vs_oracle(forced)
+
+
+def test_golden_kats(forced):
+    parity.test_golden_hamming_kats(forced)
+
+
+@pytest.mark.parametrize("nbytes,key_words", [(8, 1), (8, 2), (16, 2), (32, 2), (13, 1)])
+def test_within_fixed_length(forced, nbytes, key_words):
+    within.test_within_fixed_length_vs_numpy(forced, nbytes, key_words)
+
+
+def test_within_nphd_prefix_match(forced):
+    within.test_within_nphd_mixed_lengths_is_the_prefix_match(forced)
+
+
+def test_within_overflow_fallback(forced):
+    within.test_within_radius_beyond_the_candidate_buffer_takes_the_exact_fallback(forced)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_sequences(forced, seed):
+    fuzz.test_random_operation_sequences(forced, seed)
+
+
+def test_search_many(forced):
+    many.test_search_many_equals_the_oracle_in_every_order(forced)
+
+
+@pytest.mark.parametrize("nbytes,metric", [(8, 0), (32, 1), (20, 0)])
+def test_large_batch_under_default_thresholds(hip_engine, nbytes, metric):
+    """1 000 queries over 400 003 rows: levels and collect pass run on the matrix cores, bit-exact against the oracle."""
+    rng = np.random.default_rng(31 + nbytes)
+    n, nq, k = 400_003, 1000, 10
+    mw = (nbytes + 7) // 8
+    words = parity._rand_words(rng, n, mw, nbytes)
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(3)
+    q = parity._rand_words(rng, nq, mw, nbytes)
+    near = rng.integers(0, n, size=nq // 2)
+    q[: nq // 2] = words[near]
+    q[: nq // 2, 0] ^= np.uint64(1) << rng.integers(40, 64, size=nq // 2).astype(np.uint64)      # one bit off a stored code
+    lens = np.full(n, nbytes, dtype=np.uint8) if metric else None
+    qlens = np.full(nq, nbytes, dtype=np.uint8) if metric else None
+    t = hip_engine.open_table(metric, 1, nbytes)
+    try:
+        t.add(keys, words, lens)
+        before = hip_engine.stats()["mfma_launches"]
+        got = t.search(q, qlens, k)
+        assert hip_engine.stats()["mfma_launches"] > before
+        exp = oracle_topk(metric, keys, words, lens, q, qlens, k, fixed_nbytes=0 if metric else nbytes)
+        for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+            np.testing.assert_array_equal(g, e, err_msg=name)
+        # the XOR + popcount kernel returns the same bits
+        hip_engine.set_option("mfma", 0)
+        try:
+            other = t.search(q, qlens, k)
+        finally:
+            hip_engine.set_option("mfma", 1)
+        for g, e, name in zip(other, exp, ("keys", "hamming", "prefix_bits", "count")):
+            np.testing.assert_array_equal(g, e, err_msg="valu " + name)
+    finally:
+        t.drop()

@@ -10,8 +10,8 @@
 // per 1 024 queries; the bound is the matrix pipe (64 cycles per 1 024 pairs per SIMD) instead of 4.5 VALU
 // lane-operations per pair.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o proto_mfma_scan proto_mfma_scan.hip
-// Run  : ./proto_mfma_scan [rows] [queries] [tau] [blocks_per_cu]     (prints ms, pairs/s, check vs a brute-force kernel)
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -o proto_mfma_scan proto_mfma_scan.hip
+// Run  : ./proto_mfma_scan [rows] [queries] [tau] [blocks_per_cu] [tiles per wave step: 1|2] [variant 0|1|2]     (prints ms, pairs/s, check vs a brute-force kernel)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -72,7 +72,9 @@ __global__ void checksum(P p, unsigned long long* sum) {
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 
 // LDS image: B fragments [G][2][64] v4i (group, mfma, lane) | thr[nq] | popc[nq]
-template <int GROUPS>
+//   T    row tiles (32 rows each) per wave and step: the B fragments, the threshold and the compare are shared by T tiles
+//   VAR  0 = the real thing; 1 = results not folded (MFMA + LDS floor); 2 = B fragments read once (MFMA + VALU floor)
+template <int GROUPS, int T, int VAR>
 __global__ __launch_bounds__(256) void mfma_scan(const P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v4i* lb = reinterpret_cast<v4i*>(smem);
@@ -101,76 +103,97 @@ __global__ __launch_bounds__(256) void mfma_scan(const P p) {
     }
     __syncthreads();
 
-    const uint64_t ntiles = p.n_rows / 32;
+    const uint64_t nsteps = p.n_rows / (32 * T);
     const uint64_t stride = (uint64_t)gridDim.x * 4;
     const uint32_t* col32 = reinterpret_cast<const uint32_t*>(p.col);
-    uint64_t tile = (uint64_t)blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
+    uint64_t step = (uint64_t)blockIdx.x * 4 + wave;
+    if (step >= nsteps) return;
 
-    // a lane's 16 results of a group all belong to query g*32 + (lane & 31): fold them, compare once
-    auto reduce = [&](const v16i& acc, int thr, int g, uint64_t t) {
-        int m = min3i(acc[0], acc[1], acc[2]);
-        m = min3i(m, acc[3], acc[4]);
-        m = min3i(m, acc[5], acc[6]);
-        m = min3i(m, acc[7], acc[8]);
-        m = min3i(m, acc[9], acc[10]);
-        m = min3i(m, acc[11], acc[12]);
-        m = min3i(m, acc[13], acc[14]);
-        m = min(m, acc[15]);
+    struct Acc { v16i t[T]; };
+    // a lane's 16 results per tile all belong to query g*32 + (lane & 31): fold them, compare once
+    auto reduce = [&](const Acc& acc, int thr, int g, uint64_t st) {
+        int m;
+        if constexpr (VAR == 1) {
+            m = acc.t[0][0];
+            if constexpr (T == 2) m = min(m, acc.t[1][0]);
+        } else {
+            m = min3i(acc.t[0][0], acc.t[0][1], acc.t[0][2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) m = min3i(m, acc.t[0][i], acc.t[0][i + 1]);
+            if constexpr (T == 2) {
+                m = min3i(m, acc.t[0][15], acc.t[1][0]);
+#pragma unroll
+                for (int i = 1; i < 15; i += 2) m = min3i(m, acc.t[1][i], acc.t[1][i + 1]);
+                m = min(m, acc.t[1][15]);
+            } else {
+                m = min(m, acc.t[0][15]);
+            }
+        }
         if (__builtin_expect(m <= thr, 0)) {
             // rare: row of result `reg` = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), query = g * 32 + (lane & 31)
             const uint32_t q = g * 32 + r;
             const int pc = lpop[q];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                if (acc[reg] <= thr) {
-                    const uint64_t row = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    const uint32_t hd = (uint32_t)(acc[reg] + pc);
-                    const uint32_t slot = atomicAdd(&p.cnt[q], 1u);
-                    if (slot < p.cap) p.cand[(uint64_t)q * p.cap + slot] = ((uint64_t)hd << 48) | row;
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (acc.t[t][reg] <= thr) {
+                        const uint64_t row = (st * T + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const uint32_t hd = (uint32_t)(acc.t[t][reg] + pc);
+                        const uint32_t slot = atomicAdd(&p.cnt[q], 1u);
+                        if (slot < p.cap) p.cand[(uint64_t)q * p.cap + slot] = ((uint64_t)hd << 48) | row;
+                    }
                 }
-            }
         }
     };
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto mm = [&](const v4i& a0, const v4i& a1, const v4i& b0, const v4i& b1) {
-        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, zero, 0, 0, 0);
-        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc, 0, 0, 0);
+    v4i a[T][2];
+    auto mm = [&](Acc& acc, const v4i& b0, const v4i& b1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc.t[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t][0], b0, zero, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc.t[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t][1], b1, acc.t[t], 0, 0, 0);
     };
     const v4i* lbl = lb + lane;
     const int* lt = lthr + r;
 
-    uint32_t x = col32[(tile * 32 + r) * 2 + h];
-    for (; tile < ntiles; tile += stride) {
-        const uint64_t nt = tile + stride < ntiles ? tile + stride : tile;
-        const uint32_t xn = col32[(nt * 32 + r) * 2 + h];      // next tile's rows, in flight during this tile
-        v4i a0, a1;
+    uint32_t x[T], xn[T];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a0[j] = (x >> j) & 0x01010101u; a1[j] = (x >> (j + 4)) & 0x01010101u; }
+    for (int t = 0; t < T; ++t) x[t] = col32[((step * T + t) * 32 + r) * 2 + h];
+    for (; step < nsteps; step += stride) {
+        const uint64_t ns = step + stride < nsteps ? step + stride : step;
+#pragma unroll
+        for (int t = 0; t < T; ++t) xn[t] = col32[((ns * T + t) * 32 + r) * 2 + h];      // next rows, in flight during this step
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[t][0][j] = (x[t] >> j) & 0x01010101u; a[t][1][j] = (x[t] >> (j + 4)) & 0x01010101u; }
         // software pipeline over the groups: the MFMAs of group g+1 are issued before the results of group g are
         // folded, and the B fragments of group g+2 are requested as soon as the buffer they land in has been consumed
         v4i by0 = lbl[0], by1 = lbl[64];
         int thrY = lt[0];
         v4i bx0 = lbl[128], bx1 = lbl[192];
         int thrX = lt[32];
-        v16i accY = mm(a0, a1, by0, by1), accX;
+        Acc accY, accX;
+        mm(accY, by0, by1);
 #pragma unroll 1
         for (int g = 0; g < GROUPS - 2; g += 2) {
-            accX = mm(a0, a1, bx0, bx1);                                  // group g + 1
-            by0 = lbl[(g + 2) * 128]; by1 = lbl[(g + 2) * 128 + 64];
+            mm(accX, bx0, bx1);                                  // group g + 1
+            if constexpr (VAR != 2) { by0 = lbl[(g + 2) * 128]; by1 = lbl[(g + 2) * 128 + 64]; }
             const int thrYn = lt[(g + 2) * 32];
-            reduce(accY, thrY, g, tile);
+            reduce(accY, thrY, g, step);
             thrY = thrYn;
-            accY = mm(a0, a1, by0, by1);                                  // group g + 2
-            bx0 = lbl[(g + 3) * 128]; bx1 = lbl[(g + 3) * 128 + 64];
+            mm(accY, by0, by1);                                  // group g + 2
+            if constexpr (VAR != 2) { bx0 = lbl[(g + 3) * 128]; bx1 = lbl[(g + 3) * 128 + 64]; }
             const int thrXn = lt[(g + 3) * 32];
-            reduce(accX, thrX, g + 1, tile);
+            reduce(accX, thrX, g + 1, step);
             thrX = thrXn;
         }
-        accX = mm(a0, a1, bx0, bx1);
-        reduce(accY, thrY, GROUPS - 2, tile);
-        reduce(accX, thrX, GROUPS - 1, tile);
-        x = xn;
+        mm(accX, bx0, bx1);
+        reduce(accY, thrY, GROUPS - 2, step);
+        reduce(accX, thrX, GROUPS - 1, step);
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[t] = xn[t];
     }
 }
 
@@ -198,18 +221,18 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dq, hq.data(), nq * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtau, ht.data(), nq * 4, hipMemcpyHostToDevice));
     P p{col, rows / 32 * 32, dq, dtau, cnt, cand, cap, nq};
-    if (nq != 1024 && nq != 512 && nq != 256) { printf("queries must be 256, 512 or 1024\n"); return 1; }
+    if (nq != 1024) { printf("queries must be 1024 in this build\n"); return 1; }
+    const int T = argc > 5 ? atoi(argv[5]) : 1;
+    const int var = argc > 6 ? atoi(argv[6]) : 0;
     const int groups = nq / 32;
     const size_t lds = (size_t)groups * 2 * 64 * 16 + (size_t)nq * 8;
+    p.n_rows = rows / 64 * 64;
+#define LAUNCH_CASE(TT, VV) if (T == TT && var == VV) { static bool once = false; if (!once) { once = true; \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<32, TT, VV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); } \
+        hipLaunchKernelGGL((mfma_scan<32, TT, VV>), dim3(cus * bpc), dim3(256), lds, 0, p); }
     auto launch = [&]() {
-        dim3 grid(cus * bpc);
-        if (groups == 32) hipLaunchKernelGGL(mfma_scan<32>, grid, dim3(256), lds, 0, p);
-        else if (groups == 16) hipLaunchKernelGGL(mfma_scan<16>, grid, dim3(256), lds, 0, p);
-        else hipLaunchKernelGGL(mfma_scan<8>, grid, dim3(256), lds, 0, p);
+        LAUNCH_CASE(1, 0) LAUNCH_CASE(1, 1) LAUNCH_CASE(1, 2) LAUNCH_CASE(2, 0) LAUNCH_CASE(2, 1) LAUNCH_CASE(2, 2)
     };
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -229,8 +252,8 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double pairs = (double)p.n_rows * nq;
-    printf("mfma_scan: rows=%llu queries=%u tau=%d blocks/CU=%d lds=%zu B : %.3f ms  %.3e pairs/s  (%.1f cycles@2.4GHz per 1024 pairs per SIMD)  %.2f PB/s int8-ops of 5.03\n",
-           (unsigned long long)p.n_rows, nq, tau, bpc, lds, best, pairs / (best * 1e-3),
+    printf("mfma_scan T=%d var=%d: rows=%llu queries=%u tau=%d blocks/CU=%d lds=%zu B : %.3f ms  %.3e pairs/s  (%.1f cycles@2.4GHz per 1024 pairs per SIMD)  %.2f PB/s int8-ops of 5.03\n",
+           T, var, (unsigned long long)p.n_rows, nq, tau, bpc, lds, best, pairs / (best * 1e-3),
            best * 1e-3 * 2.4e9 / (pairs / 1024 / (cus * 4.0)), pairs * 128 / (best * 1e-3) / 1e15);
     // check against brute force
     std::vector<uint32_t> c1(nq), c2(nq);
