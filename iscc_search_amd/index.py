@@ -77,6 +77,25 @@ def _sp_string(s):
     return s.root if hasattr(s, "root") else s
 
 
+def _checked_limit(limit):
+    # type: (int) -> int
+    """
+    The engine returns at most ``MAX_K`` (4 096) neighbours per query.  The reference hands ``limit`` to usearch
+    unbounded (``usearch/index.py:2037``); rather than silently returning a shorter list than was asked for, a larger
+    ``limit`` is refused (ValueError -> HTTP 400, ``server/search.py:43-46``).
+    """
+    if limit > MAX_K:
+        raise ValueError(f"limit {limit} exceeds the {MAX_K} neighbours per query this backend returns")
+    return max(1, limit)
+
+
+def _check_instance_hits(count, unit_type):
+    # type: (int, str) -> None
+    """An identity (INSTANCE) match list that fills the engine's cap would be cut silently: refuse instead."""
+    if count >= MAX_K:
+        raise ValueError(f"more than {MAX_K - 1} assets share the queried {unit_type} prefix; refine the query (longer code)")
+
+
 class HipIndex:
     """One named index: host asset store + device tables."""
 
@@ -91,6 +110,7 @@ class HipIndex:
         self._unit_tables = {}  # type: Dict[str, HipNphdIndex]
         self._sp_tables = {}  # type: Dict[str, HipSimprintIndex]
         self._sp_assets = {}  # type: Dict[str, Dict[bytes, list]]   sp_type -> body -> [(sp_bytes, chunk_ptr)]
+        self._suspect = set()  # asset keys whose last device update failed half-way: their next add cleans up first
         self.dirty = False
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -152,7 +172,7 @@ class HipIndex:
                 stored = asset.model_copy(update={"simprints": None})
                 fingerprints = {t: self._fingerprint(lst) for t, lst in (asset.simprints or {}).items()}
                 # idempotent re-add: nothing to do when entry and simprints are already indexed identically
-                if existing is not None and existing == stored and all(
+                if existing is not None and key not in self._suspect and existing == stored and all(
                     self._fingerprint_of(t, id_obj.body) == fp for t, fp in fingerprints.items()
                 ):
                     continue
@@ -170,16 +190,32 @@ class HipIndex:
                     sp_decoded[sp_type] = [(codec.decode_base64(sp.simprint), pack_chunk_pointer(id_obj.body, sp.offset, sp.size)) for sp in sp_list]
                 staged.append((key, id_obj.body, stored, unit_map, sp_decoded))
 
+            # host state is published first (searches read it without the lock) and rolled back if a device call fails,
+            # so that a failed batch can simply be retried (the reference keeps its no-op gate honest the same way:
+            # _nphd_units_present / _simprints_present_in_derived, usearch/index.py:539-679)
+            undo = []                              # (key, body, old entry, old unit map, {sp_type: old pairs})
+            dropped = {}  # type: Dict[str, list]  unit_type -> keys whose update no longer carries that type
             for key, body, stored, unit_map, sp_decoded in staged:
+                old_units = self._asset_units.get(key, {})
+                undo.append((key, body, self._assets.get(key), self._asset_units.get(key),
+                             {t: self._sp_assets.get(t, {}).get(body) for t in sp_decoded}))
                 self._assets[key] = stored
                 for unit_type, ubody in unit_map.items():
                     unit_batches.setdefault(unit_type, {})[key] = ubody
+                # an INSTANCE unit the new version no longer carries must leave its table: left behind it would keep
+                # prefix-matching as a 1.0 identity hit (usearch/index.py:338-348).  Similarity units the update drops
+                # stay, as in the reference, which removes only from the indexes of the types the NEW version carries (:432-441)
+                for unit_type in old_units:
+                    if unit_type not in unit_map and unit_type.startswith("INSTANCE_"):
+                        dropped.setdefault(unit_type, []).append(key)
                 self._asset_units[key] = unit_map
                 for sp_type, pairs in sp_decoded.items():
                     self._sp_table(sp_type, len(pairs[0][0]) * 8)
                     old = self._sp_assets[sp_type].pop(body, None)
                     if old is not None:
                         sp_deleted.setdefault(sp_type, []).extend(ptr for _, ptr in old)
+                    if key in self._suspect:       # rows of a half-applied earlier attempt may sit under the NEW pointers
+                        sp_deleted.setdefault(sp_type, []).extend(ptr for _, ptr in pairs)
                     self._sp_assets[sp_type][body] = pairs
                     keys_b, vecs_b = sp_batches.setdefault(sp_type, ([], []))
                     for sp_bytes, ptr in pairs:
@@ -187,17 +223,37 @@ class HipIndex:
                         vecs_b.append(np.frombuffer(sp_bytes, dtype=np.uint8))
 
             # device side: remove-before-add for updated assets, then one batched add per table
-            for unit_type, items in unit_batches.items():
-                table = self._unit_table(unit_type)
-                to_remove = [k for k in items if k in updated_keys]
-                if to_remove:
-                    table.remove(to_remove)
-                table.add(list(items.keys()), list(items.values()))
-            for sp_type, (ckeys, vecs) in sp_batches.items():
-                table = self._sp_tables[sp_type]
-                if sp_type in sp_deleted:
-                    table.remove(sp_deleted[sp_type])
-                table.add_raw(ckeys, vecs)
+            try:
+                for unit_type, keys_gone in dropped.items():
+                    self._unit_tables[unit_type].remove(keys_gone)
+                for unit_type, items in unit_batches.items():
+                    table = self._unit_table(unit_type)
+                    to_remove = [k for k in items if k in updated_keys or k in self._suspect]
+                    if to_remove:
+                        table.remove(to_remove)
+                    table.add(list(items.keys()), list(items.values()))
+                for sp_type, (ckeys, vecs) in sp_batches.items():
+                    table = self._sp_tables[sp_type]
+                    if sp_type in sp_deleted:
+                        table.remove(sp_deleted[sp_type])
+                    table.add_raw(ckeys, vecs)
+            except Exception:
+                for key, body, old_entry, old_units, old_sp in undo:
+                    if old_entry is None:
+                        self._assets.pop(key, None)
+                        self._asset_units.pop(key, None)
+                    else:
+                        self._assets[key] = old_entry
+                        self._asset_units[key] = old_units if old_units is not None else {}
+                    for sp_type, pairs in old_sp.items():
+                        if pairs is None:
+                            self._sp_assets.get(sp_type, {}).pop(body, None)
+                        else:
+                            self._sp_assets[sp_type][body] = pairs
+                    self._suspect.add(key)
+                raise
+            for key, *_ in staged:
+                self._suspect.discard(key)
             if staged:
                 self.dirty = True
             return results
@@ -226,7 +282,7 @@ class HipIndex:
     def _search_similarity_unit(self, unit_type, body, limit):
         # type: (str, bytes, int) -> Dict[int, float]
         """``usearch/index.py:2024-2045``: score = max(0, 1 - NPHD)."""
-        matches = self._unit_tables[unit_type].search(np.frombuffer(body, dtype=np.uint8), count=min(limit, MAX_K))
+        matches = self._unit_tables[unit_type].search(np.frombuffer(body, dtype=np.uint8), count=_checked_limit(limit))
         out = {}
         for key, distance in zip(matches.keys, matches.distances):
             out[int(key)] = max(0.0, 1.0 - float(distance))
@@ -243,6 +299,7 @@ class HipIndex:
         if table is None:
             return {}
         m = table.search_within(np.frombuffer(body, dtype=np.uint8), count=MAX_K, max_hamming=0)
+        _check_instance_hits(len(m.keys), unit_type)
         return {int(key): 1.0 for key in m.keys}
 
     def _search_units(self, units, limit):
@@ -262,12 +319,13 @@ class HipIndex:
             if unit.unit_type.startswith("INSTANCE_"):
                 requests.append((index._table, words, nbytes, MAX_K, 0))
             else:
-                requests.append((index._table, words, nbytes, min(limit, MAX_K), None))
+                requests.append((index._table, words, nbytes, _checked_limit(limit), None))
             plan.append(unit.unit_type)
         aggregated = {}  # type: Dict[int, Dict[str, float]]
         for unit_type, (keys, ham, pbits, cnt) in zip(plan, self._engine.search_many(requests)):
             c = int(cnt[0])
             if unit_type.startswith("INSTANCE_"):
+                _check_instance_hits(c, unit_type)
                 for key in keys[0, :c]:
                     aggregated.setdefault(int(key), {})[unit_type] = 1.0
                 continue
@@ -381,22 +439,29 @@ class HipIndex:
         # type: (str) -> None
         with self._lock:
             os.makedirs(path, exist_ok=True)
-            with open(os.path.join(path, "assets.jsonl.tmp"), "w") as f:
-                for key, asset in self._assets.items():
-                    f.write(json.dumps({"key": key, "asset": asset.model_dump(mode="json", exclude_none=True)}, separators=(",", ":")) + "\n")
-            os.replace(os.path.join(path, "assets.jsonl.tmp"), os.path.join(path, "assets.jsonl"))
+            # sharded index (hip:///path?devices=N): every rank writes its own table shards, rank 0 the host files
+            writer = getattr(self._engine, "rank", 0) == 0
+            if writer:
+                with open(os.path.join(path, "assets.jsonl.tmp"), "w") as f:
+                    for key, asset in self._assets.items():
+                        f.write(json.dumps({"key": key, "asset": asset.model_dump(mode="json", exclude_none=True)}, separators=(",", ":")) + "\n")
+                os.replace(os.path.join(path, "assets.jsonl.tmp"), os.path.join(path, "assets.jsonl"))
             for unit_type, table in self._unit_tables.items():
                 table.save(os.path.join(path, "units", unit_type))
             for sp_type, table in self._sp_tables.items():
                 table.save(os.path.join(path, "simprints", sp_type))
-            meta = {
-                "format": 1, "realm_id": self._realm_id, "assets": len(self._assets),
-                "unit_types": sorted(self._unit_tables),
-                "simprint_types": {t: tbl.ndim for t, tbl in self._sp_tables.items()},
-            }
-            with open(os.path.join(path, "index.json.tmp"), "w") as f:
-                json.dump(meta, f)
-            os.replace(os.path.join(path, "index.json.tmp"), os.path.join(path, "index.json"))
+            if writer:
+                meta = {
+                    "format": 1, "realm_id": self._realm_id, "assets": len(self._assets),
+                    "unit_types": sorted(self._unit_tables),
+                    "simprint_types": {t: tbl.ndim for t, tbl in self._sp_tables.items()},
+                    "ranks": getattr(self._engine, "world_size", 1),
+                }
+                with open(os.path.join(path, "index.json.tmp"), "w") as f:
+                    json.dump(meta, f)
+                os.replace(os.path.join(path, "index.json.tmp"), os.path.join(path, "index.json"))
+            if hasattr(self._engine, "all_gather_object"):
+                self._engine.all_gather_object(None)       # nobody returns before rank 0 has written index.json
             self.dirty = False
 
     @classmethod
@@ -406,6 +471,8 @@ class HipIndex:
 
         with open(os.path.join(path, "index.json")) as f:
             meta = json.load(f)
+        if meta.get("ranks", 1) != getattr(engine, "world_size", 1):
+            raise ValueError(f"snapshot at {path} was written by {meta.get('ranks', 1)} rank(s), this manager runs {getattr(engine, 'world_size', 1)}")
         idx = cls(engine, options)
         idx._realm_id = meta["realm_id"]
         assets_file = os.path.join(path, "assets.jsonl")
@@ -425,8 +492,12 @@ class HipIndex:
         for sp_type, ndim in meta["simprint_types"].items():
             table = idx._sp_table(sp_type, ndim)
             table.load(os.path.join(path, "simprints", sp_type))
-            # the host-side per-asset chunk lists are derived from the stored rows
-            for ckey, sp_bytes in table.rows():
+            # the host-side per-asset chunk lists are derived from the stored rows (of every shard: they are host state
+            # every rank keeps whole)
+            rows = list(table.rows())
+            if hasattr(engine, "all_gather_object"):
+                rows = sorted(r for part in engine.all_gather_object(rows) for r in part)
+            for ckey, sp_bytes in rows:
                 body = unpack_chunk_pointer(ckey)[0]
                 idx._sp_assets[sp_type].setdefault(body, []).append((sp_bytes, ckey))
         return idx
@@ -462,6 +533,11 @@ class HipIndexManager:
             raise ValueError(f"HipIndexManager requires a hip:// URI, got '{uri}'")
         qs = parse_qs(parsed.query)
         self.device_id = int(qs.get("device", ["0"])[0])
+        # hip:///?devices=N  -> the index row-sharded over N GPUs: one process per GPU under torch.distributed, every
+        #                       rank runs the same calls (iscc_search_amd/sharded_engine.py)
+        self.devices = int(qs.get("devices", ["1"])[0])
+        if self.devices < 1:
+            raise ValueError(f"devices must be >= 1, got {self.devices}")
         # hip:///            -> volatile (like memory://)
         # hip:///abs/path    -> snapshots under that directory: loaded lazily, written by flush()/close()
         self.base_path = parsed.path if parsed.path not in ("", "/") else None
@@ -482,7 +558,20 @@ class HipIndexManager:
         if self._engine is None:
             from iscc_search_amd.engine import HipEngine   # raises loudly without library / GPU
 
-            self._engine = HipEngine(self.device_id)
+            if self.devices > 1:
+                import torch.distributed as dist
+
+                from iscc_search_amd.sharded_engine import ShardedEngine
+
+                if not dist.is_initialized() or dist.get_world_size() != self.devices:
+                    raise ValueError(
+                        f"hip:///?devices={self.devices} needs {self.devices} processes under torch.distributed (one per GPU: "
+                        f"python -m torch.distributed.run --nproc-per-node {self.devices} ...), initialised BEFORE the index is opened"
+                    )
+                local = int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+                self._engine = ShardedEngine(HipEngine(local), device=f"cuda:{local}")
+            else:
+                self._engine = HipEngine(self.device_id)
         return self._engine
 
     def _index(self, name):

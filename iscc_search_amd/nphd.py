@@ -355,16 +355,20 @@ class HipIndex128:
             out.append(Matches(words_to_key128(keys[q, :c]), ham[q, :c].astype(np.float32), ham[q, :c].copy(), pbits[q, :c].copy()))
         return out[0] if single else BatchMatches(out)
 
-    def search_arrays(self, vectors, count=10):
-        # type: (np.ndarray, int) -> tuple[np.ndarray, np.ndarray, np.ndarray]
+    def search_arrays(self, vectors, count=10, max_hamming=None):
+        # type: (np.ndarray, int, int | None) -> tuple[np.ndarray, np.ndarray, np.ndarray]
         """
         The same search as raw arrays, for callers that filter before they materialise keys:
         (key words uint64 [nq, count, 2], differing bits uint32 [nq, count], valid entries uint32 [nq]).
+        With ``max_hamming`` only rows within that radius are listed (nearest first).
         """
         if count < 1:
             raise ValueError("`count` must be >= 1")
         q_words, _ = pack_bytes(self._vectors(vectors), self._table.max_words)
-        keys, ham, _, cnt = self._table.search(q_words, None, count)
+        if max_hamming is None:
+            keys, ham, _, cnt = self._table.search(q_words, None, count)
+        else:
+            keys, ham, _, cnt = self._table.search_within(q_words, None, count, int(max_hamming))
         return keys, ham, cnt
 
     def search_within(self, vectors, count, max_hamming=0):

@@ -142,8 +142,22 @@ class HipSimprintIndex:
         if not simprints or len(self._index) == 0:
             return []
         queries = np.stack([np.frombuffer(s, dtype=np.uint8) for s in simprints])
-        count = min(MAX_K, max(1, limit * self.oversampling_factor))   # the engine's k ceiling (4096)
-        key_words, ham, cnt = self._index.search_arrays(queries, count=count)
+        count = max(1, limit * self.oversampling_factor)
+        if count <= MAX_K:
+            key_words, ham, cnt = self._index.search_arrays(queries, count=count)
+        else:
+            # The reference asks usearch for `count` neighbours unbounded (usearch_core.py:164); the engine returns at most
+            # MAX_K per query.  Only neighbours scoring >= threshold survive the filter below, i.e. rows within a fixed
+            # radius: list exactly those.  A list that still fills the cap cannot be represented -- refuse, never truncate.
+            radius = self.ndim
+            while radius > 0 and 1.0 - radius / self.ndim < threshold:
+                radius -= 1
+            key_words, ham, cnt = self._index.search_arrays(queries, count=MAX_K, max_hamming=radius)
+            if int(cnt.max(initial=0)) >= MAX_K and count > MAX_K:
+                raise ValueError(
+                    f"limit {limit} x oversampling {self.oversampling_factor} = {count} neighbours per simprint exceeds the "
+                    f"{MAX_K} this backend returns, and a query simprint has that many stored chunks within the match threshold"
+                )
 
         # Threshold first, on the whole [queries x count] block at once: the reference walks every neighbour in
         # Python (usearch_core.py:175-196); most of an oversampled list fails the threshold.  Same arithmetic

@@ -21,6 +21,47 @@ SEED = 0x1511CC00
 K = 10
 
 
+def slab_oracle_topk(rows, nbytes, q, k, metric=0, key_words=1, slab=25_000_000, seed=SEED):
+    """
+    The oracle over a synthetic table too large for one host array: exact top-k per slab of rows, merged on the host
+    under (distance, key).  Every row has ``nbytes`` bytes, so the distance order is the Hamming order.
+    """
+    mw = (nbytes + 7) // 8
+    qn = np.full(len(q), nbytes, dtype=np.uint8) if metric else None
+    best = [[] for _ in range(len(q))]
+    for lo in range(0, rows, slab):
+        n = min(slab, rows - lo)
+        words = np.stack([oracle_splitmix64_fill(n, seed, first=lo, stride=4, lane=w) for w in range(mw)], axis=1)
+        if nbytes % 8:
+            words[:, -1] &= np.uint64((0xFFFFFFFFFFFFFFFF << (8 * (8 - nbytes % 8))) & 0xFFFFFFFFFFFFFFFF)
+        rk = np.arange(lo, lo + n, dtype=np.uint64)
+        keys = np.stack([np.zeros(n, dtype=np.uint64), rk], axis=1) if key_words == 2 else rk
+        lens = np.full(n, nbytes, dtype=np.uint8) if metric else None
+        kk, hh, pp, cc = oracle_topk(metric, keys, words, lens, q, qn, k, fixed_nbytes=0 if metric else nbytes)
+        for i in range(len(q)):
+            c = int(cc[i])
+            low = kk[i, :c, 1] if key_words == 2 else kk[i, :c]
+            best[i].extend(zip(hh[i, :c].tolist(), low.tolist()))
+    out_k = np.zeros((len(q), k), dtype=np.uint64)
+    out_h = np.zeros((len(q), k), dtype=np.uint32)
+    out_c = np.zeros(len(q), dtype=np.uint32)
+    for i, cand in enumerate(best):
+        top = sorted(cand)[:k]
+        out_c[i] = len(top)
+        out_h[i, : len(top)] = [h for h, _ in top]
+        out_k[i, : len(top)] = [key for _, key in top]
+    return out_k, out_h, out_c
+
+
+def check_lists(keys, ham, pbits, cnt, k, bits, key_words=1):
+    """Size-independent properties of a result block: full, sorted by (distance, key), distinct keys, prefix length."""
+    assert np.all(cnt == k) and np.all(pbits == bits)
+    low = keys[..., 1] if key_words == 2 else keys
+    for i in range(ham.shape[0]):
+        pairs = list(zip(ham[i].tolist(), low[i].tolist()))
+        assert pairs == sorted(pairs) and len(set(low[i].tolist())) == k, i
+
+
 def _queries(nq):
     rng = np.random.default_rng(99)
     q = rng.integers(0, 2**64, size=(nq, 1), dtype=np.uint64)
@@ -58,14 +99,19 @@ def test_fullsize_properties_and_oracle_spot_check(hip_engine, big):
     again = big.search(q, None, K)
     for a, b in zip((keys, ham, pbits, cnt), again):
         np.testing.assert_array_equal(a, b)
-    # the VALU-bound T_q = 16 kernel returns the same bits
-    hip_engine.set_option("queries_per_pass", 16)
+    # 64 queries over 100 M rows run on the matrix cores by default; the XOR + popcount kernel (T_q = 8 and the
+    # VALU-bound T_q = 16) returns the same bits
+    assert hip_engine.stats()["mfma_launches"] > 0
+    hip_engine.set_option("mfma", 0)
     try:
-        other = big.search(q, None, K)
+        for tq in (16, 8):
+            hip_engine.set_option("queries_per_pass", tq)
+            other = big.search(q, None, K)
+            for a, b in zip((keys, ham, pbits, cnt), other):
+                np.testing.assert_array_equal(a, b)
     finally:
         hip_engine.set_option("queries_per_pass", 8)
-    for a, b in zip((keys, ham, pbits, cnt), other):
-        np.testing.assert_array_equal(a, b)
+        hip_engine.set_option("mfma", 1)
     # bit-exact against the oracle over all 100 M rows for a few queries (one planted, rest random)
     words = oracle_splitmix64_fill(ROWS, SEED, stride=4).reshape(ROWS, 1)
     row_keys = np.arange(ROWS, dtype=np.uint64)
@@ -208,3 +254,139 @@ def test_concurrent_single_query_callers_are_combined_and_exact(hip_engine, big)
     sequential_s = time.perf_counter() - t0
     print(f"64 single-query searches over 100M rows: sequential {sequential_s*1e3:.1f} ms, 64 threads {concurrent_s*1e3:.1f} ms")
     assert concurrent_s < max(5 * sequential_s, 0.5)
+
+
+def _planted(rng, nq, rows, nbytes, every=4):
+    """Random queries; every `every`-th is a stored row with f low bits of its last byte flipped."""
+    mw = (nbytes + 7) // 8
+    q = rng.integers(0, 2**64, size=(nq, mw), dtype=np.uint64)
+    shift = np.uint64(8 * (8 - nbytes % 8) % 64)
+    if nbytes % 8:
+        q[:, -1] &= np.uint64(0xFFFFFFFFFFFFFFFF) << shift
+    planted = {}
+    for j in range(0, nq, every):
+        r = int(rng.integers(0, rows))
+        f = (0, 1, 3, 7)[(j // every) % 4]
+        for w in range(mw):
+            q[j, w] = oracle_splitmix64_fill(1, SEED, first=r, stride=4, lane=w)[0]
+        if nbytes % 8:
+            q[j, -1] &= np.uint64(0xFFFFFFFFFFFFFFFF) << shift
+        q[j, -1] ^= np.uint64(f) << shift
+        planted[j] = (r, bin(f).count("1"))
+    return q, planted
+
+
+def test_config3_100m_x_256bit_nphd_1024_queries(hip_engine):
+    """BASELINE config 3: 100 M x 256-bit ISCC-UNITs in an NPHD table, one batch of 1 024 queries."""
+    nb, nq = 32, 1024
+    t = hip_engine.open_table(1, 1, nb)
+    try:
+        t.add_synthetic(nb, ROWS, SEED)
+        q, planted = _planted(np.random.default_rng(3), nq, ROWS, nb)
+        qn = np.full(nq, nb, dtype=np.uint8)
+        before = hip_engine.stats()
+        keys, ham, pbits, cnt = t.search(q, qn, K)
+        after = hip_engine.stats()
+        assert after["mfma_launches"] > before["mfma_launches"] and after["fallback_queries"] == before["fallback_queries"]
+        check_lists(keys, ham, pbits, cnt, K, 256)
+        for j, (r, f) in planted.items():
+            assert int(ham[j, 0]) == f and int(keys[j, 0]) == r, (j, ham[j, :3], keys[j, :3])
+        # idempotent, and the XOR + popcount kernel (W = 4, queries in LDS, several stretches of 4 M rows) agrees for every query
+        again = t.search(q, qn, K)
+        hip_engine.set_option("mfma", 0)
+        try:
+            valu = t.search(q, qn, K)
+        finally:
+            hip_engine.set_option("mfma", 1)
+        for a, b, c in zip((keys, ham, pbits, cnt), again, valu):
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(a, c)
+        # bit-exact against the oracle (25 M-row slabs merged on the host) for a planted and a few random queries
+        pick = [0, 1, 2, 3, 515, 1023]
+        ek, eh, ec = slab_oracle_topk(ROWS, nb, q[pick], K, metric=1)
+        np.testing.assert_array_equal(keys[pick], ek)
+        np.testing.assert_array_equal(ham[pick], eh)
+        np.testing.assert_array_equal(cnt[pick], ec)
+    finally:
+        t.drop()
+
+
+@pytest.mark.parametrize("nbytes", [8, 16, 32])
+def test_config5_10m_simprint_tables_128bit_keys_k400(hip_engine, nbytes):
+    """BASELINE config 5: 10 M chunk fingerprints per ndim (64 / 128 / 256 bit), 128-bit keys, 512 queries, count = 400."""
+    rows, nq, k = 10_000_000, 512, 400
+    t = hip_engine.open_table(0, 2, nbytes)
+    try:
+        t.add_synthetic(nbytes, rows, SEED)
+        q, planted = _planted(np.random.default_rng(50 + nbytes), nq, rows, nbytes, every=8)
+        keys, ham, pbits, cnt = t.search(q, None, k)
+        check_lists(keys, ham, pbits, cnt, k, nbytes * 8, key_words=2)
+        assert np.all(keys[..., 0] == 0)
+        for j, (r, f) in planted.items():
+            assert int(ham[j, 0]) == f and int(keys[j, 0, 1]) == r, (j, ham[j, :3], keys[j, :3])
+        hip_engine.set_option("mfma", 0)
+        try:
+            valu = t.search(q, None, k)
+        finally:
+            hip_engine.set_option("mfma", 1)
+        for a, b in zip((keys, ham, pbits, cnt), valu):
+            np.testing.assert_array_equal(a, b)
+        pick = [0, 1, 2, 3, 100, 257, 510, 511]
+        ek, eh, ec = slab_oracle_topk(rows, nbytes, q[pick], k, key_words=2, slab=10_000_000)
+        np.testing.assert_array_equal(keys[pick][..., 1], ek)
+        np.testing.assert_array_equal(ham[pick], eh)
+        np.testing.assert_array_equal(cnt[pick], ec)
+    finally:
+        t.drop()
+
+
+def test_config4_one_billion_rows_on_one_gpu_and_as_eight_merged_shards(hip_engine):
+    """
+    BASELINE config 4's index (1 B x 64-bit, 16 GB with keys) on ONE GPU: properties for 256 queries, the oracle (eight
+    125 M-row slabs merged on the host) for a few, and the same rows as eight row-range shards -- one table each, their
+    device-resident top-k merged by merge_kernel exactly as the eight ranks of a node merge after the all-gather --
+    equal to the unsharded answer.  (The RCCL transport itself needs eight GPUs: the driver's scaling run.)
+    """
+    import torch
+
+    from iscc_search_amd.sharded import block_bytes, shard_range
+
+    rows, nq = 1_000_000_000, 256
+    q, planted = _planted(np.random.default_rng(4), nq, rows, 8)
+    whole = hip_engine.open_table(0, 1, 8)
+    try:
+        whole.add_synthetic(8, rows, SEED)
+        keys, ham, pbits, cnt = whole.search(q, None, K)
+        check_lists(keys, ham, pbits, cnt, K, 64)
+        for j, (r, f) in planted.items():
+            assert int(ham[j, 0]) == f and int(keys[j, 0]) == r, (j, ham[j, :3], keys[j, :3])
+        again = whole.search(q[:16], None, K)          # a small batch: the HBM-streaming XOR + popcount kernel over 8 GB of codes
+        for a, b in zip((keys[:16], ham[:16], pbits[:16], cnt[:16]), again):
+            np.testing.assert_array_equal(a, b)
+        pick = [0, 1, 2, 3, 255]
+        ek, eh, ec = slab_oracle_topk(rows, 8, q[pick], K, slab=125_000_000)
+        np.testing.assert_array_equal(keys[pick], ek)
+        np.testing.assert_array_equal(ham[pick], eh)
+        np.testing.assert_array_equal(cnt[pick], ec)
+    finally:
+        whole.drop()
+    shards = []
+    try:
+        rec_bytes, blk = block_bytes(nq, K)
+        gathered = torch.empty(8 * blk, dtype=torch.uint8, device="cuda:0")
+        for rank in range(8):
+            lo, hi = shard_range(rows, rank, 8)
+            t = hip_engine.open_table(0, 1, 8)
+            shards.append(t)
+            t.add_synthetic(8, hi - lo, SEED, first_row=lo)
+            base = gathered.data_ptr() + rank * blk
+            t.search_device(q, None, K, base, base + rec_bytes)
+            t.drop()
+        shards = []
+        torch.cuda.synchronize()
+        merged = hip_engine.merge_device(8, nq, K, 1, gathered.data_ptr(), gathered.data_ptr() + rec_bytes, blk, blk)
+        for a, b in zip((keys, ham, pbits, cnt), merged):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        for t in shards:
+            t.drop()

@@ -72,3 +72,48 @@ def test_two_processes_two_shards_one_gpu(tmp_path):
                 np.testing.assert_array_equal(z[f"s{i}"], want_s[i], err_msg=f"rank {rank} search field {i}")
                 np.testing.assert_array_equal(z[f"w{i}"], want_w[i], err_msg=f"rank {rank} within field {i}")
     assert int(want_w[3].sum()) > 0          # the radius admits rows, so the within lists are not trivially empty
+
+
+def _manager_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"          # both ranks share the box's one GPU
+    import json
+
+    import torch.distributed as dist
+
+    from iscc_search_amd.index import HipIndexManager
+    from test_sharded_manager_gloo import scenario
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        uri = f"hip://{out_dir}/store?devices={world}"
+        out = scenario(HipIndexManager(uri), reopen=lambda: HipIndexManager(uri))       # the product engine: HipEngine + ShardedEngine
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+            json.dump(out, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_manager_on_two_processes_equals_the_oracle_backed_unsharded_manager(tmp_path):
+    """``hip:///path?devices=2`` end to end on the GPU (N1): every rank's protocol answers equal the oracle engine's."""
+    import json
+
+    import torch.multiprocessing as mp
+
+    from iscc_search_amd.index import HipIndexManager
+    from oracle_engine import OracleEngine
+    from test_sharded_manager_gloo import scenario
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_manager_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    uri = f"hip://{tmp_path}/single/store"
+    want = json.loads(json.dumps(scenario(HipIndexManager(uri, engine=OracleEngine()), reopen=lambda: HipIndexManager(uri, engine=OracleEngine()))))
+    for rank in range(2):
+        with open(tmp_path / f"rank{rank}.json") as f:
+            got = json.load(f)
+        assert len(got) == len(want)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g == w, f"rank {rank}, answer {i}"

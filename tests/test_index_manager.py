@@ -284,6 +284,71 @@ def test_update_replaces_vectors(manager, rng):
     assert [m.iscc_id for m in manager.search_assets("t", IsccQuery(iscc_code=new.iscc_code)).global_matches] == [new.iscc_id]
 
 
+def test_update_that_drops_the_instance_unit_stops_matching_it(manager, rng):
+    """usearch/index.py:338-348: an INSTANCE row the update no longer carries is deleted."""
+    manager.create_index(IsccIndex(name="t"))
+    full = make_asset(rng, 0)
+    other = make_asset(rng, 1)
+    manager.add_assets("t", [full, other])
+    instance_unit = [u for u in full.units if codec.Iscc(u).unit_type.startswith("INSTANCE_")][0]
+    hit = manager.search_assets("t", IsccQuery(units=[instance_unit])).global_matches
+    assert [m.iscc_id for m in hit] == [full.iscc_id] and hit[0].score == 1.0
+    kept = [u for u in full.units if u != instance_unit]
+    without = full.model_copy(update={"units": kept, "iscc_code": None})      # no INSTANCE unit: no ISCC-CODE can be composed
+    assert manager.add_assets("t", [without])[0].status == Status.updated
+    assert manager.search_assets("t", IsccQuery(units=[instance_unit])).global_matches == []
+    # the similarity units it still carries keep matching
+    assert [m.iscc_id for m in manager.search_assets("t", IsccQuery(units=kept[:1])).global_matches][:1] == [full.iscc_id]
+
+
+def test_failed_device_update_is_rolled_back_and_can_be_retried(rng):
+    """host state must not run ahead of the device, or the idempotent gate makes the asset unsearchable for good."""
+    from helpers import sp
+
+    engine = OracleEngine()
+    m = HipIndexManager("hip:///", engine=engine)
+    m.create_index(IsccIndex(name="t"))
+    s0 = bytes(range(16))
+    first = make_asset(rng, 0)
+    m.add_assets("t", [first])
+    second = make_asset(rng, 0, simprints={"CONTENT_TEXT_V0": [sp(s0, 0, 10)]})
+    idx = m._indexes["t"]
+    real_add = type(idx._unit_table("DATA_NONE_V0")).add
+    calls = {"n": 0}
+
+    def failing_add(self, keys, vectors):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise MemoryError("hipMalloc failed (injected)")
+        return real_add(self, keys, vectors)
+
+    type(idx._unit_table("DATA_NONE_V0")).add = failing_add
+    try:
+        with pytest.raises(MemoryError):
+            m.add_assets("t", [second])
+    finally:
+        type(idx._unit_table("DATA_NONE_V0")).add = real_add
+    # the host still describes the version that is fully on the device ...
+    assert m.get_asset("t", first.iscc_id).iscc_code == first.iscc_code
+    # ... and the SAME batch goes through on retry (no idempotent-skip) and becomes searchable in every table
+    assert m.add_assets("t", [second])[0].status == Status.updated
+    assert [x.iscc_id for x in m.search_assets("t", IsccQuery(iscc_code=second.iscc_code)).global_matches] == [second.iscc_id]
+    assert m.search_assets("t", IsccQuery(iscc_code=first.iscc_code)).global_matches == []
+    chunk = m.search_assets("t", IsccQuery(simprints={"CONTENT_TEXT_V0": [codec.encode_base64(s0)]})).chunk_matches
+    assert [c.iscc_id for c in chunk] == [second.iscc_id] and chunk[0].types["CONTENT_TEXT_V0"].matches == 1
+    m.close()
+
+
+def test_limits_beyond_the_engine_cap_are_refused_not_truncated(manager, rng):
+    """the reference passes `limit` on unbounded (usearch/index.py:2037); a silent cut is not acceptable."""
+    manager.create_index(IsccIndex(name="t"))
+    a = make_asset(rng, 0)
+    manager.add_assets("t", [a])
+    assert len(manager.search_assets("t", IsccQuery(iscc_code=a.iscc_code), limit=4096).global_matches) == 1
+    with pytest.raises(ValueError, match="exceeds the 4096 neighbours"):
+        manager.search_assets("t", IsccQuery(iscc_code=a.iscc_code), limit=4097)
+
+
 def test_close_is_idempotent(rng):
     m = HipIndexManager("hip:///", engine=OracleEngine())
     m.create_index(IsccIndex(name="t"))

@@ -175,3 +175,30 @@ def test_simprint_update_replaces_old_chunks(manager):
     assert hit.chunk_matches[0].score == 1.0
     miss = manager.search_assets("t", IsccQuery(simprints={"CONTENT_TEXT_V0": [codec.encode_base64(old)]}))
     assert all(m.score < 1.0 for m in miss.chunk_matches)
+
+
+def test_large_limit_lists_everything_within_the_threshold_or_refuses(engine):
+    """
+    ``count = limit * oversampling`` beyond the engine's 4 096-neighbour cap: the threshold turns the
+    request into a radius, so the answer is still complete; a radius that would hold more than the cap is refused.
+    """
+    idx = HipSimprintIndex(engine, ndim=64, oversampling_factor=20)
+    base = bytes([0xAA] * 8)
+    keys, vecs = [], []
+    for i in range(40):
+        keys.append(pack_chunk_pointer((1000 + i).to_bytes(8, "big"), 0, 10))
+        vecs.append(np.frombuffer(flip_bits(base, i % 5), dtype=np.uint8))
+    idx.add_raw(keys, vecs)
+    small = idx.search_raw([base], limit=10, threshold=0.9, total_assets=40, detailed=True)
+    big = idx.search_raw([base], limit=1000, threshold=0.9, total_assets=40, detailed=True)          # 20 000 neighbours asked for
+    assert len(big) == 40 and [r.iscc_id_body for r in big[:10]] == [r.iscc_id_body for r in small]
+    assert all(r.chunks[0].score >= 0.9 for r in big) and min(r.chunks[0].score for r in big) == 1.0 - 4 / 64
+    assert idx.search_raw([base], limit=1000, threshold=0.97, total_assets=40) != [] and len(idx.search_raw([base], limit=1000, threshold=0.97)) == 16
+    with pytest.raises(ValueError, match="exceeds the"):
+        many_k, many_v = [], []
+        for i in range(4200):
+            many_k.append(pack_chunk_pointer((5000 + i).to_bytes(8, "big"), 1, 1))
+            many_v.append(np.frombuffer(base, dtype=np.uint8))
+        idx.add_raw(many_k, many_v)
+        idx.search_raw([base], limit=1000, threshold=0.9)
+    idx.close()
