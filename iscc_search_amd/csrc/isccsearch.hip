@@ -439,6 +439,7 @@ struct Batch {
             h->stats.mfma_pair_words += rows * (uint64_t)nq * j.W;
             return 0;
         }
+        if (sp.n_rows / (uint64_t)tile_rows_for((int)j.W) >= (1ull << 31)) return fail(-E2BIG, "segment of %llu rows exceeds the scan kernel's 2^31 tiles", (unsigned long long)sp.n_rows);
         launch_scan((int)j.W, j.mask, tq, mode, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups, sample), groups), h->stream, sp);
         return 0;
     }

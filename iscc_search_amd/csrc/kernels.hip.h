@@ -224,7 +224,11 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
     };
     const uint32_t mlo = sgpr(p.mask_lo), mhi = sgpr(p.mask_hi);
 
-    const uint64_t n_full = p.n_rows / TILE;
+    // Tile numbers are 32-bit ON PURPOSE: the loop tests below are then scalar compares (s_cmp_lt_u32) and scalar branches.
+    // With 64-bit counters hipcc did the unsigned compares on the VALU (there is no s_cmp_lt_u64), parked the operand in a
+    // register pair it also uses for load destinations, and structurised the `break`s with EXEC tests -- a control-flow
+    // graph tools/audit_kernels.py cannot prove the asm-load invariants on.  The host refuses segments of >= 2^31 tiles.
+    const uint32_t n_full = (uint32_t)(p.n_rows / TILE);
     // per-lane byte offset inside a tile (constant over the loop): wave w reads U KiB contiguous per column,
     // load u of a lane sits u*1024 bytes further (immediate offset); the tile base stays scalar.
     //   row(u, lane, r) = tile*TILE + wave*(U*128) + u*128 + lane*2 + r
@@ -232,18 +236,18 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
     const uint32_t voff = wave * (uint32_t)(U * 1024) + lane * 16u;
     const uint32_t row_in_tile = wave * (uint32_t)(U * 128) + lane * 2u;
 
-    auto load_tile = [&](u32x4 (&v)[U][W], uint64_t tile) {
+    auto load_tile = [&](u32x4 (&v)[U][W], uint32_t tile) {
         const void* tb[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             // uniform tile base, forced into an SGPR pair for the saddr operand
-            const uint64_t ta = reinterpret_cast<uint64_t>(p.col[w]) + tile * (uint64_t)(TILE * 8);
+            const uint64_t ta = reinterpret_cast<uint64_t>(p.col[w]) + (uint64_t)tile * (uint64_t)(TILE * 8);
             tb[w] = reinterpret_cast<const void*>(((uint64_t)sgpr((uint32_t)(ta >> 32)) << 32) | sgpr((uint32_t)ta));
         }
         load_tile_asm<NT, U, W>(v, tb, voff);
     };
 
-    auto process = [&](const u32x4 (&v)[U][W], uint64_t tile) {
+    auto process = [&](const u32x4 (&v)[U][W], uint32_t tile) {
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < TQ; ++q) {
@@ -286,7 +290,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
             // query from the SGPR-resident queries (fully unrolled: no memory loads, no dynamic register
             // indexing), so a tile that takes this path costs about two plain tiles instead of the
             // ~16 a load-per-query loop cost.
-            const uint64_t base = tile * TILE + row_in_tile;
+            const uint64_t base = (uint64_t)tile * TILE + row_in_tile;
             // launder the row registers: without this the compiler merges the rescoring below with
             // the fast path above (common subexpressions) and keeps all TQ*U*2 accumulators alive
             u32x4 r[U][W];
@@ -333,17 +337,17 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
     // between; more outstanding operations only make the counted wait stricter, never weaker.)
     if constexpr (prefetch_depth<W>() == 1) {
         u32x4 va[U][W], vb[U][W];
-        uint64_t tile = p.row_begin / TILE + blockIdx.x;
+        uint32_t tile = (uint32_t)(p.row_begin / TILE) + blockIdx.x;
         if (tile < n_full) {
-            const uint64_t last = n_full - 1;
+            const uint32_t last = n_full - 1;
             load_tile(va, tile);
             for (;;) {
-                const uint64_t t1 = tile + gridDim.x;
+                const uint32_t t1 = tile + gridDim.x;
                 load_tile(vb, t1 < n_full ? t1 : last);
                 wait_tile<U * W>(va);
                 process(va, tile);
                 if (t1 >= n_full) break;
-                const uint64_t t2 = t1 + gridDim.x;
+                const uint32_t t2 = t1 + gridDim.x;
                 load_tile(va, t2 < n_full ? t2 : last);
                 wait_tile<U * W>(vb);
                 process(vb, t1);
@@ -356,11 +360,11 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
         // two tiles ahead: three buffers rotate, 2*U*W younger loads are outstanding at every wait
         static_assert(prefetch_depth<W>() == 2, "prefetch depth");
         u32x4 va[U][W], vb[U][W], vc[U][W];
-        uint64_t t = p.row_begin / TILE + blockIdx.x;
-        const uint64_t G = gridDim.x;
+        uint32_t t = (uint32_t)(p.row_begin / TILE) + blockIdx.x;
+        const uint32_t G = gridDim.x;
         if (t < n_full) {
-            const uint64_t last = n_full - 1;
-            auto clamp = [&](uint64_t x) { return x < n_full ? x : last; };
+            const uint32_t last = n_full - 1;
+            auto clamp = [&](uint32_t x) { return x < n_full ? x : last; };
             load_tile(va, t);
             load_tile(vb, clamp(t + G));
             for (;;) {
@@ -384,7 +388,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
 
     // tail rows [n_full*TILE, n_rows): one row per thread, handled by the first block of the group
     if (blockIdx.x == 0) {
-        for (uint64_t row = n_full * TILE + tid; row < p.n_rows; row += BLOCK) {
+        for (uint64_t row = (uint64_t)n_full * TILE + tid; row < p.n_rows; row += BLOCK) {
             uint32_t lo[W], hi[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) {

@@ -1,0 +1,86 @@
+"""
+tools/audit_kernels.py is part of the build (``make audit``): it must accept the pipelined load / counted-wait structure of
+the scan kernels and reject the three ways that structure can silently break.  Synthetic gfx950 assembly, CPU tier.
+"""
+
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "audit_kernels.py")
+
+RES = """remark: Function Name: _ZN3isk11scan_kernelILi1ELb0ELi8ELi0ELb1EEEvNS_10ScanParamsE
+remark:     TotalSGPRs: 96
+remark:     VGPRs: 74
+remark:     AGPRs: 0
+remark:     ScratchSize [bytes/lane]: {scratch}
+remark:     Occupancy [waves/SIMD]: 6
+remark:     SGPRs Spill: 4
+remark:     VGPRs Spill: {spill}
+"""
+
+ASM = """_ZN3isk11scan_kernelILi1ELb0ELi8ELi0ELb1EEEvNS_10ScanParamsE:
+	s_load_dwordx2 s[0:1], s[4:5], 0x0
+	;;#ASMSTART
+	{nop}
+	global_load_dwordx4 v[2:5], v1, s[0:1] offset:0 nt
+	;;#ASMEND
+.LBB0_1:
+	;;#ASMSTART
+	s_nop 4
+	global_load_dwordx4 v[6:9], v1, s[2:3] offset:0 nt
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_xor_b32_e32 v10, v2, v20
+	{extra}
+	s_cmp_lt_u32 s8, s9
+	s_cbranch_scc0 .LBB0_3
+	;;#ASMSTART
+	s_nop 4
+	global_load_dwordx4 v[2:5], v1, s[0:1] offset:0 nt
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_xor_b32_e32 v11, v6, v20
+	s_cmp_lt_u32 s8, s9
+	s_cbranch_scc1 .LBB0_1
+.LBB0_3:
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def run(tmp_path, nop="s_nop 4", extra="s_nop 0", scratch=0, spill=0):
+    a, r = tmp_path / "k.s", tmp_path / "k.res"
+    a.write_text(ASM.format(nop=nop, extra=extra))
+    r.write_text(RES.format(scratch=scratch, spill=spill))
+    p = subprocess.run([sys.executable, TOOL, str(a), str(r)], capture_output=True, text=True)
+    return p.returncode, p.stdout
+
+
+def test_accepts_the_pipelined_structure(tmp_path):
+    rc, out = run(tmp_path)
+    assert rc == 0 and "3 asm load groups in 1 kernels" in out, out
+
+
+def test_rejects_a_copy_of_an_in_flight_destination(tmp_path):
+    rc, out = run(tmp_path, extra="v_mov_b32_e32 v30, v7")          # v7 is being loaded while the first tile is scored
+    assert rc == 1 and "touches a destination of the load group" in out, out
+    rc, out = run(tmp_path, extra="v_mov_b32_e32 v30, v3")          # v3 was retired by the counted wait: fine
+    assert rc == 0, out
+
+
+def test_rejects_missing_wait_state_pad_scratch_and_spills(tmp_path):
+    rc, out = run(tmp_path, nop="s_nop 0")
+    assert rc == 1 and "does not open with s_nop 4" in out
+    rc, out = run(tmp_path, scratch=16)
+    assert rc == 1 and "scratch" in out
+    rc, out = run(tmp_path, spill=2)
+    assert rc == 1 and "VGPR spills" in out

@@ -47,12 +47,12 @@ def test_factory_branch_of_options_get_index(no_gpu, tmp_path):
     src = "def get_index(uri, search_opts):\n    parsed = urlparse(uri)\n" + "\n".join(body) + "\n    raise ValueError('unsupported')\n"
     ns = {"urlparse": urlparse}
     exec(compile(src, "INTEGRATION.md#1a", "exec"), ns)
-    opts = types.SimpleNamespace(match_threshold_units=0.8, match_threshold_simprints=0.7, confidence_exponent=3,
-                                 oversampling_factor=10, max_dim=128)
+    # exactly the knobs SearchOptions has (iscc_search/options.py:139-164): an attribute the hunk reads beyond them fails here
+    opts = types.SimpleNamespace(match_threshold_units=0.8, match_threshold_simprints=0.7, confidence_exponent=3, oversampling_factor=10)
     for uri in ("hip:///", f"hip://{tmp_path}/store?device=0"):
         m = ns["get_index"](uri, opts)
         assert isinstance(m, HipIndexManager)
-        assert (m._opts.match_threshold_units, m._opts.confidence_exponent, m._opts.oversampling_factor, m._opts.max_dim) == (0.8, 3, 10, 128)
+        assert (m._opts.match_threshold_units, m._opts.confidence_exponent, m._opts.oversampling_factor, m._opts.max_dim) == (0.8, 3, 10, 256)
         m.create_index(IsccIndex(name="x"))
         assert m.get_index("x").assets == 0
         m.close()
