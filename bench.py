@@ -15,8 +15,8 @@ Prints ONE JSON line on rank 0.
 
 `roofline` describes the dominant kernel of the TIMED steps, measured with HIP events on the library's own stream
 inside the timed region:
-  * batches of >= 64 queries run the collect scan on the int8 matrix cores (csrc/mfma_scan.hip): bound "mfma",
-    achieved = (rows x queries x 64-bit words) x 128 int8 operations / launch time, peak = dense int8 MFMA rate;
+  * batches of >= 32 queries run the collect scan on the matrix cores in FP4 (csrc/mfma_scan.hip): bound "mfma",
+    achieved = (rows x queries x 64-bit words) x 128 operations / launch time, peak = dense FP4 MFMA rate;
   * with `--opt mfma=0` the XOR + popcount kernel runs: cache-blocked it is bound by VALU issue (bound "valu",
     in (row, query, word) triples per second against the measured issue rates of v_xor / v_bcnt / v_min3), and with
     `--opt stretch_mb=0` every pass streams from HBM (bound "hbm", algorithmic bytes / time).
@@ -50,11 +50,14 @@ MASK64 = (1 << 64) - 1
 # peaks (MI355X_MICROARCH.md; profiles/r02_micro_valu2.txt for the integer VALU issue rates)
 HBM_PEAK_GBS = 8000.0                       # HBM3E spec; 6.29 TB/s is the guide's measured copy ceiling
 SIMDS, CLOCK_HZ = 1024, 2.4e9               # 256 CUs x 4 SIMDs, max clock
-MFMA_I8_PEAK_TOPS = SIMDS * 2048 * CLOCK_HZ / 1e12      # v_mfma_i32_32x32x32_i8: 32*32*32*2 ops per 32 cycles per SIMD = 5 033 TOP/s dense
-# XOR + popcount kernel, per wave64 and (row, query, word): 2 v_xor (2 cycles each with VGPR sources) + 2 v_bcnt (4 each)
-# + half a v_min3 (4) = 14 issue cycles for 64 triples
-VALU_CYCLES_PER_64_TRIPLES = 14.0
-VALU_PEAK_GTRIPLES = SIMDS * CLOCK_HZ * 64 / VALU_CYCLES_PER_64_TRIPLES / 1e9
+MFMA_FP4_PEAK_TOPS = SIMDS * 4096 * CLOCK_HZ / 1e12     # v_mfma_scale_f32_32x32x64_f8f6f4 (FP4): 32*32*64*2 ops per 32 cycles per SIMD = 10 066 TOP/s dense
+# XOR + popcount kernel, per wave64 and (row, query): 2 v_xor + 2 v_bcnt per 64-bit word and half a v_min3 per pair, each at the
+# 4 cycles a wave64 instruction takes in this mix (profiles/r02_micro_valu3.txt: 35 cycles per 9 instructions)
+
+
+def valu_peak_gtriples(words):
+    """(row, query, word) triples per second at full VALU issue: 64 lanes / ((4 + 0.5 / W) instructions x 4 cycles) per SIMD."""
+    return SIMDS * CLOCK_HZ * 64 / ((4.0 + 0.5 / words) * 4.0) / 1e9
 PMC_PROFILE = os.path.join("profiles", "r02_pmc_fetch_size.json")
 
 
@@ -99,17 +102,20 @@ def roofline_of(st, args, words, regime):
     mfma = st["scan_mfma_launches"] == launches
     if mfma:
         ops = st["scan_pair_words"] * 128.0                                # 64 multiply-adds per triple
-        out.update({"bound": "mfma", "kernel": "isk::mfma_scan_kernel<W=%d> (v_mfma_i32_32x32x32_i8)" % words,
-                    "achieved": ops / secs / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8, dense)"})
+        # SQ counters of the same kernel (profiles/r02_pmc_sq_mfma_scan.json): the matrix pipe is busy ~45 % of the cycles and
+        # vector issue (the fold: 16 results per lane per 1 024 pairs + the MFMAs' own issue slots) ~80 %; the chip holds ~2.0 GHz
+        out.update({"bound": "mfma", "kernel": "isk::mfma_scan_kernel<W=%d> (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 operands)" % words,
+                    "achieved": ops / secs / 1e12, "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s (FP4, dense)",
+                    "co_limiter": "vector issue: the per-result fold shares the SIMD's issue port with the MFMAs"})
     elif regime.startswith("streaming"):
         out.update({"bound": "hbm", "kernel": "isk::scan_adapt_kernel / scan_kernel (XOR + popcount), one pass of T_q queries per table read",
                     "achieved": st["scan_bytes"] / 1e9 / secs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "measured_copy_ceiling_GBs": 6290.0, "measured_read_ceiling_GBs": 7050.0})
     else:
         out.update({"bound": "valu", "kernel": "isk::scan_adapt_kernel / scan_kernel (XOR + popcount), rows served by L2 / Infinity Cache",
-                    "achieved": st["scan_pair_words"] / 1e9 / secs, "peak": VALU_PEAK_GTRIPLES, "unit": "G (row, query, word) triples/s",
-                    "peak_derivation": "1024 SIMDs x 2.4 GHz x 64 lanes / 14 issue cycles per 64 triples (2 v_xor @ 2 + 2 v_bcnt @ 4 + 1/2 v_min3 @ 4; "
-                                       "profiles/r02_micro_valu2.txt)",
+                    "achieved": st["scan_pair_words"] / 1e9 / secs, "peak": valu_peak_gtriples(words), "unit": "G (row, query, word) triples/s",
+                    "peak_derivation": "1024 SIMDs x 2.4 GHz x 64 lanes / ((2 v_xor + 2 v_bcnt per word + 1/2 v_min3 per pair) x 4 cycles per wave64 "
+                                       "instruction in this mix; profiles/r02_micro_valu3.txt)",
                     "algorithmic_GBs": st["scan_bytes"] / 1e9 / secs})
     out["frac"] = out["achieved"] / out["peak"]
     return out
@@ -155,6 +161,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: RCCL prints a version banner to stdout when a communicator is created, so everything
+    # below runs with fd 1 pointing at stderr and the line is written to the real stdout at the end
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -193,7 +204,7 @@ def main():
     words = (args.nbytes + 7) // 8
     engine = HipEngine(local_rank)
     engine.set_option("queries_per_pass", args.tq)
-    opts = {"mfma": 1, "stretch_mb": 128, "mfma_min_queries": 64}
+    opts = {"mfma": 1, "stretch_mb": 128, "mfma_min_queries": 32}
     for kv in args.opt:
         name, _, val = kv.partition("=")
         engine.set_option(name, int(val))
@@ -304,7 +315,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "i8 (0/1 x +-1 products accumulated in i32)" if mfma_on else "u64",
+        "dtype": "fp4 (e2m1 0/1 x +-1 products, f32 accumulation: exact integers)" if mfma_on else "u64",
         "data": "synthetic",
         "config": {
             "workload": f"{args.rows} x {args.nbytes * 8}-bit codes, brute-force {'NPHD' if nphd else 'Hamming'} k={args.k}, "
@@ -315,7 +326,7 @@ def main():
             "k": args.k,
             "queries_per_step": args.queries,
             "queries_per_pass": args.tq,
-            "scan": "int8 MFMA" if mfma_on else "XOR + popcount",
+            "scan": "FP4 MFMA" if mfma_on else "XOR + popcount",
             "parallelism": f"row-shard x{world}, one all-gather of per-shard top-k",
         },
         "roofline": roof,
@@ -330,8 +341,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, q, words, first)
         out["parity_checked_queries"] = out["cpu_baseline"]["parity_checked_queries"]
 
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     table.drop()
     engine.close()
     if dist.is_initialized():

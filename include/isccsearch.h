@@ -86,8 +86,8 @@ typedef struct isccsearch_stats {
     uint32_t queries_per_pass;/* T_q: queries held in SGPRs per streaming pass                */
     uint32_t compute_units;   /* CUs of the device                                            */
     uint64_t freq_builds;     /* document-frequency columns (re)built by isccsearch_get_freq  */
-    uint64_t mfma_launches;   /* scan launches (levels + collect) that ran on the int8 matrix cores           */
-    uint64_t mfma_pair_words; /* (row, query, 64-bit word) triples those launches scored: 128 int8 ops each   */
+    uint64_t mfma_launches;   /* scan launches (levels + collect) that ran on the matrix cores (FP4)         */
+    uint64_t mfma_pair_words; /* (row, query, 64-bit word) triples those launches scored: 128 operations each   */
     uint64_t scan_pair_words; /* (row, REAL query, word) triples of the collect launches counted in scan_launches / scan_ms */
     uint64_t scan_mfma_launches; /* how many of scan_launches ran on the matrix cores                          */
 } isccsearch_stats;

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libisccsearch_hip.so")
+# ISCC_HIP_LIB: another build of the same library (kernel experiments); the default is the in-tree product build
+LIB_PATH = os.environ.get("ISCC_HIP_LIB") or os.path.join(_HERE, "csrc", "libisccsearch_hip.so")
 
 METRIC_HAMMING = 0
 METRIC_NPHD = 1

@@ -157,10 +157,12 @@ struct isccsearch_handle {
     bool repick = true;            // re-derive the threshold after every collect stretch but the last
     uint32_t fold_tau = 11;        // 64-bit codes: groups whose thresholds are all <= this take the folded fast path (0: off)
     uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
-    // large batches: the scan as an int8 matrix-core contraction (mfma_scan.hip) instead of XOR + popcount on the VALU
+    // large batches: the scan as an FP4 matrix-core contraction (mfma_scan.hip) instead of XOR + popcount on the VALU
     bool mfma = true;
-    uint32_t mfma_min_queries = 64;   // batches below this stay on the VALU kernel (HBM-bound up to ~11 queries per pass)
+    uint32_t mfma_min_queries = 32;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
+                                      // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms; 16 queries cost the same 0.49 ms against ~0.3 ms)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
+    uint64_t mfma_level_growth = 8;   // threshold levels when the scan runs on the matrix cores (k <= 64)
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
     // scratch
@@ -432,7 +434,8 @@ struct Batch {
             const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad);
             const uint32_t chunks = (nq_pad + g * 32 - 1) / (g * 32);
             const uint64_t steps = (rows + 63) / 64;
-            const uint64_t bx = std::max<uint64_t>(1, std::min<uint64_t>((steps + 3) / 4, std::max<uint32_t>(1, (uint32_t)h->cus * 2 / chunks)));
+            const uint64_t wpb = isk::mfma_waves_per_block();
+            const uint64_t bx = std::max<uint64_t>(1, std::min<uint64_t>((steps + wpb - 1) / wpb, std::max<uint32_t>(1, (uint32_t)h->cus * isk::mfma_blocks_per_cu((int)j.W, g) / chunks)));
             const int e = isk::launch_mfma_scan((int)j.W, mode, (uint32_t)bx, g, h->stream, sp);
             if (e) return fail(-EIO, "mfma scan: hipFuncSetAttribute failed: %s", hipGetErrorString((hipError_t)e));
             h->stats.mfma_launches += 1;
@@ -567,6 +570,7 @@ struct Batch {
             //    64x when there are so few query groups that launch gaps outweigh candidate handling; less
             //    when k * growth would not fit the candidate buffer).  No row is read twice.
             uint64_t growth = (groups <= 2 && k <= 64) ? std::max<uint64_t>(64, h->level_growth) : h->level_growth;
+            if (use_mfma(s.n) && k <= 64) growth = h->mfma_level_growth;   // matrix-core launches: see the option's comment
             if (k >= 256) growth = std::min<uint64_t>(growth, 2);   // simprint-sized k: candidate handling dominates, +10 % with short levels
             // a stretch `growth` times the rows seen so far brings ~growth * (rows at or under tau) candidates, and the
             // tie class at tau can make that 2.3x k (ratio of consecutive binomial tails): keep it inside the buffer
@@ -851,6 +855,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
+    if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
     return fail(-EINVAL, "unknown option '%s'", name);

@@ -50,10 +50,12 @@ static_assert(sizeof(Record) == 24, "record layout");
 template <int W> struct TileCfg { static constexpr int U = (W == 1) ? 4 : (W == 2 ? 2 : 1); };
 template <int W> constexpr int tile_rows() { return BLOCK * 2 * TileCfg<W>::U; }
 // Where the TQ queries of a group live while a block scans.
-//   VGPRs (every lane holds the same TQ*W*2 query dwords) as long as they fit beside the two tiles in flight: up to 32
-//   registers.  Round 1 kept them in SGPRs; an SGPR source halves the issue rate of v_xor (see vgpr() above).
+//   SGPRs (scalar operands of v_xor, nothing to load in the loop) as long as they FIT: TQ*W*2 query dwords + TQ
+//   biases + the loop's own scalars must stay under ~100 registers, beyond that hipcc spills them into VGPR lanes
+//   and every use costs a v_readlane -- a VALU instruction, the very resource the kernel is short of (W=4, TQ=8:
+//   52 spilled SGPRs = +19 % VALU work per tile; TQ=16: 211).  (VGPR-resident queries were measured and bring nothing:
+//   see vgpr() above.)
 //   LDS otherwise: one broadcast ds_read_b128 per four query dwords per tile, on the LDS pipe, into VGPR operands.
-//   The thresholds (bias) stay in SGPRs: they feed v_bcnt's accumulator input, a 4-cycle op either way.
 template <int W, int TQ> constexpr bool queries_in_lds() { return TQ * W >= 24; }
 template <int W> constexpr int query_vecs() { return (2 * W + 3) / 4; }   // u32x4 slots per query in LDS
 // tiles in flight ahead of the one being scored (experiment switch; 1 = double buffering)
@@ -75,10 +77,13 @@ __device__ __forceinline__ uint32_t bcnt_s(uint32_t x, uint32_t acc_sgpr) { retu
 __device__ __forceinline__ uint32_t bcnt_v(uint32_t x, uint32_t acc) { return (uint32_t)__builtin_popcount(x) + acc; }
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return pin(min(min(a, b), c)); }
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-// A wave-uniform value kept in a VGPR on purpose.  gfx950 issues the plain two-operand integer ops (v_xor, v_and, v_add,
-// shifts, v_mov) of a wave64 in 2 cycles when their sources are VGPRs, inline constants or literals, and in 4 when one
-// source is an SGPR (profiles/r02_micro_valu2.txt: v_xor_b32 v,v,v 2.47 cycles, v_xor_b32 v,s,v 4.09); v_bcnt, v_min3
-// and the other VOP3 integer ops take 4 either way.  So the query words the row words are XORed with live in VGPRs.
+// A wave-uniform value kept in a VGPR on purpose (experiment switch ISK_QUERIES_IN_VGPRS).  In ISOLATION gfx950 issues the
+// plain two-operand ops (v_xor, v_and, v_add, shifts, v_mov, v_fma_f32) of a wave64 in ~2.4 cycles when their sources are
+// VGPRs, inline constants or literals, and in ~4.1 when one source is an SGPR; v_bcnt, v_min3 and the other VOP3 integer ops
+// take ~4.1-4.4 either way (profiles/r02_micro_valu2.txt).  MIXED with those 4-cycle ops, as in this kernel's inner loop,
+// the fast forms gain nothing: 4 v_xor + 4 v_bcnt + 1 v_min3 take 35 cycles with the query words in VGPRs and 35 with them in
+// SGPRs (profiles/r02_micro_valu3.txt), and the kernel measured 78.8 k queries/s either way -- so the queries stay in SGPRs,
+// which leaves the VGPRs to the tiles in flight (7 instead of 6 waves per SIMD) and streams 2 % faster (0.84 vs 0.82 of HBM).
 __device__ __forceinline__ uint32_t vgpr(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte global load: .x/.y = row r (lo, hi), .z/.w = row r+1
@@ -190,8 +195,13 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const uint64_t v = p.queries[(uint64_t)(q0 + q) * 4 + w];
+#ifdef ISK_QUERIES_IN_VGPRS
                 qlo[q][w] = vgpr((uint32_t)v);
                 qhi[q][w] = vgpr((uint32_t)(v >> 32));
+#else
+                qlo[q][w] = sgpr((uint32_t)v);
+                qhi[q][w] = sgpr((uint32_t)(v >> 32));
+#endif
             }
         }
     }

@@ -1,4 +1,4 @@
-// mfma_scan.h -- host interface of mfma_scan.hip (the int8 matrix-core form of the collect scan).
+// mfma_scan.h -- host interface of mfma_scan.hip (the matrix-core form of the collect scan: FP4 products, f32 sums).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -9,11 +9,13 @@
 
 namespace isk {
 
-constexpr int MFMA_MAX_LDS = 80 * 1024;   // dynamic LDS ceiling requested for the kernels: two blocks per CU (160 KB)
+constexpr int MFMA_MAX_LDS = 64 * 1024;   // dynamic LDS ceiling requested for the kernels (a chunk needs <= 40 KB)
 
 // query groups (32 queries each, an even number) one block keeps in LDS for W compared words
 uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad);
 size_t mfma_lds_bytes(int W, uint32_t groups);
+uint32_t mfma_waves_per_block();   // a wave takes 64 rows per step
+uint32_t mfma_blocks_per_cu(int W, uint32_t groups);   // resident blocks per CU (LDS and register limits)
 // grid = (blocks_x, chunks of groups * 32 queries); returns 0 or a hipError_t from the attribute call (check
 // hipGetLastError() for the launch itself, as with every other kernel)
 int launch_mfma_scan(int W, int mode, uint32_t blocks_x, uint32_t groups, hipStream_t st, const ScanParams& p);

@@ -1,24 +1,30 @@
-// mfma_scan.hip -- the collect scan for LARGE query batches on the int8 matrix cores of gfx950 (MI355X).
+// mfma_scan.hip -- the collect scan for LARGE query batches on the matrix cores of gfx950 (MI355X).
 //
 // Same contract as scan_kernel (kernels.hip.h): for every row of [row_begin, n_rows) and every query, append
 // (hamming, row) to the query's candidate list when hamming over the compared prefix <= tau_q
 // (reference call sites: iscc_search/indexes/usearch/index.py:2037, iscc_search/indexes/simprint/usearch_core.py:165;
 // metric: docs/explanation/similarity-search.md:24-29).  What differs is the arithmetic:
 //
-//   hamming(row, q) = popc(q) + dot(row bits as 0/1, query bits as +1/-1)            (exact integers)
+//   hamming(row, q) = popc(q) + dot(row bits as 0/1, query bits as +1/-1)            (exact small integers)
 //
-// so the (rows x queries x bits) work is a dense int8 contraction.  The XOR + popcount kernel needs 4.5 VALU
-// instructions per (row, query, 64-bit word) -- two of them v_bcnt, which gfx950 issues at one wave64 per 4 cycles --
-// and is VALU-bound from ~11 queries per pass on.  Here a wave owns T = 2 tiles of 32 rows:
-// each lane expands ITS 32 bits of one row per word into 32 bytes of 0/1 (the A operands of two
-// v_mfma_i32_32x32x32_i8), once per step, and then walks every query group of the block's chunk.  A group is 32
-// queries pre-expanded to +1/-1 bytes in LDS (two ds_read_b128 per lane and word); 2*W MFMAs per tile give the 32 x 32
-// dot products; a lane's 16 results per tile all belong to ONE query (C/D column = lane & 31), so 16 v_min3_i32 fold
-// them and one compare against thr_q = tau_q - popc(q) decides whether the lane enters the rare emit path.
-// Masked prefixes (NPHD between codes of different lengths) cost nothing: the query bytes beyond the prefix are 0.
+// so the (rows x queries x bits) work is a dense contraction.  The XOR + popcount kernel needs 4.5 VALU instructions per
+// (row, query, 64-bit word), each issuing at one wave64 per ~4 cycles per SIMD, and is VALU-bound from ~11 queries per
+// pass on.  Here the products run on the matrix pipe in its cheapest format: FP4 (e2m1: 0x2 = +1,
+// 0xA = -1, 0x0 = 0) through v_mfma_scale_f32_32x32x64_f8f6f4 with both block scales 2^0 -- ONE instruction (32 cycles)
+// per 32 rows x 32 queries x 64 bits, f32 accumulation, exact because every partial sum is an integer of magnitude
+// <= 256.  (The int8 form, v_mfma_i32_32x32x32_i8, needs two instructions of the same length per word and measured 1.44x
+// slower: profiles/r02_proto_mfma_scan.txt.)
 //
-// The bound is the matrix pipe: 64 * W cycles per 1 024 (row, query) pairs per SIMD, against ~290 * W VALU cycles.
-// Rows cross the memory system once per chunk of up to 1 024 / W queries.  Measured numbers: DESIGN.md section 4.
+// A wave owns T = 2 tiles of 32 rows: each lane expands ITS 32 bits of one row per word into 32 nibbles (4 VGPRs, the A
+// operand), once per step, and then walks every query group of the block's chunk.  A group is 32 queries pre-expanded to
+// +1/-1 nibbles in LDS (one ds_read_b128 per lane and word); W MFMAs per tile give the 32 x 32 dot products; a lane's 16
+// results per tile all belong to ONE query (C/D column = lane & 31), so 16 v_min3_f32 fold the two tiles and one compare
+// against thr_q = tau_q - popc(q) decides whether the lane enters the rare emit path.  Masked prefixes (NPHD between codes
+// of different lengths) cost nothing: the query nibbles beyond the prefix are 0.
+//
+// What bounds it is vector ISSUE: the fold (16 values per lane per 1 024 pairs, two per v_min3) and the MFMAs share the
+// SIMD's issue port (~50 cycles per 1 024 pairs and word against 32 of matrix-pipe time); the XOR + popcount kernel needs
+// ~290.  Rows cross the memory system once per chunk of up to 1 024 queries.  Measured numbers: DESIGN.md section 4.
 //
 // Built with -mllvm -amdgpu-mfma-vgpr-form=1: hipcc otherwise puts the accumulators in AGPRs and pays one
 // v_accvgpr_read per result before the fold (16 extra VALU instructions per tile and group).
@@ -29,45 +35,51 @@
 namespace isk {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int MT = 2;   // row tiles (32 rows) per wave and step
+constexpr int MT = 2;                 // row tiles (32 rows) per wave and step
+constexpr int MBLOCK = 256;           // 4 waves; a chunk's LDS image is <= 40 KB, so LDS admits four blocks per CU
+// Registers decide: the rare emit path (both accumulator sets live + 64-bit row numbers) peaks at 130-175 VGPRs, i.e. three
+// waves per SIMD for W <= 3 and two for W = 4.  Forcing four (128 VGPRs) spilled to scratch; the prototype measured
+// 3.22 ms with three resident blocks against 3.15 ms with four (profiles/r02_proto_mfma_scan.txt) -- not worth a spill.
+template <int W> constexpr int mfma_min_waves() { return W <= 3 ? 3 : 2; }
+constexpr int FP4 = 4;                // cbsz / blgp format code of e2m1
+constexpr int SCALE_ONE = 0x7F7F7F7F; // E8M0 block scales 2^0
 
-__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 
-// Dword j (0..7) of a 32-bit half: (x >> j) & 0x01010101 holds bits j, j+8, j+16, j+24 as bytes 0/1.  MFMA 2*w + (j >> 2)
-// takes it as VGPR j & 3 of its fragment -- for rows (A) and queries (B) alike, so the k order inside the
-// instruction does not matter.
-__device__ __forceinline__ uint32_t spread(uint32_t x, int j) { return (x >> j) & 0x01010101u; }
+// Dword j (0..3) of a 32-bit half: nibble t holds bit j + 4 t.  Rows (A) and queries (B) use the same map, so the k order
+// inside the instruction does not matter; lanes 0..31 carry the low half of a word and lanes 32..63 the high half on both sides.
+__device__ __forceinline__ uint32_t nibbles(uint32_t x, int j) { return (x >> j) & 0x11111111u; }
 
-// LDS image of a chunk: B fragments [groups][2 * W][64] v4i | thr[groups * 32] | popc[groups * 32]
+// LDS image of a chunk: B fragments [groups][W][64] v4i | thr[groups * 32] (float) | popc[groups * 32]
 template <int W, int MODE>
-__global__ __launch_bounds__(BLOCK) void mfma_scan_kernel(const ScanParams p, const uint32_t groups) {
+__global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(const ScanParams p, const uint32_t groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v4i* lb = reinterpret_cast<v4i*>(smem);
-    int* lthr = reinterpret_cast<int*>(smem + (size_t)groups * (2 * W) * 64 * 16);
-    int* lpop = lthr + groups * 32;
+    float* lthr = reinterpret_cast<float*>(smem + (size_t)groups * W * 64 * 16);
+    int* lpop = reinterpret_cast<int*>(lthr + groups * 32);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
     const uint32_t q0 = blockIdx.y * groups * 32;       // first query of this block's chunk
 
-    // prologue: expand the chunk's queries to +1 / -1 bytes (0 beyond the compared prefix and for padding queries)
-    for (uint32_t i = tid; i < groups * 32 * 2 * W; i += BLOCK) {
+    // prologue: expand the chunk's queries to +1 / -1 nibbles (0 beyond the compared prefix and for padding queries)
+    for (uint32_t i = tid; i < groups * 32 * 2 * W; i += MBLOCK) {
         const uint32_t ql = i / (2 * W), rest = i % (2 * W), w = rest >> 1, hh = rest & 1;
         const uint32_t q = q0 + ql;
         const bool live = q < p.nq_pad;
         const uint64_t qw = live ? p.queries[(uint64_t)q * 4 + w] : 0;
-        uint32_t x = hh ? (uint32_t)(qw >> 32) : (uint32_t)qw;
+        const uint32_t x = hh ? (uint32_t)(qw >> 32) : (uint32_t)qw;
         uint32_t m = live ? 0xFFFFFFFFu : 0u;
         if (w == W - 1) m &= hh ? p.mask_hi : p.mask_lo;
         const uint32_t g = ql >> 5, c = ql & 31;
+        v4i frag;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t s = (0x01010101u | (spread(x, j) * 0xFEu)) & (spread(m, j) * 0xFFu);
-            reinterpret_cast<uint32_t*>(&lb[((size_t)g * (2 * W) + 2 * w + (j >> 2)) * 64 + hh * 32 + c])[j & 3] = s;
-        }
+        for (int j = 0; j < 4; ++j) frag[j] = (int)((0x22222222u | (nibbles(x, j) << 3)) & (nibbles(m, j) * 0xFu));   // bit ? -1 : +1, masked: 0
+        lb[((size_t)g * W + w) * 64 + hh * 32 + c] = frag;
     }
-    for (uint32_t ql = tid; ql < groups * 32; ql += BLOCK) {
+    for (uint32_t ql = tid; ql < groups * 32; ql += MBLOCK) {
         const uint32_t q = q0 + ql;
         int pc = 0, tau = -1;
         if (q < p.nq_pad) {
@@ -80,32 +92,30 @@ __global__ __launch_bounds__(BLOCK) void mfma_scan_kernel(const ScanParams p, co
             tau = (int)(0x7FFFFFFFu - p.bias[q]);       // BIAS_NEVER -> -1: no row can be a candidate
         }
         lpop[ql] = pc;
-        lthr[ql] = tau - pc;                            // hamming <= tau  <=>  dot <= tau - popc(q)
+        lthr[ql] = (float)(tau - pc);                   // hamming <= tau  <=>  dot <= tau - popc(q)
     }
     __syncthreads();
 
     const uint64_t first = p.row_begin / (32 * MT);                         // row_begin is a multiple of 64
     const uint64_t nsteps = (p.n_rows + 32 * MT - 1) / (32 * MT);           // the last step may be partial
-    const uint64_t stride = (uint64_t)gridDim.x * (BLOCK / 64);
-    uint64_t step = first + (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
+    const uint64_t stride = (uint64_t)gridDim.x * (MBLOCK / 64);
+    uint64_t step = first + (uint64_t)blockIdx.x * (MBLOCK / 64) + wave;
     if (step >= nsteps) return;
     const uint64_t last_row = p.n_rows - 1;
 
-    struct Acc { v16i t[MT]; };
+    struct Acc { v16f t[MT]; };
     const uint32_t* col32[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) col32[w] = reinterpret_cast<const uint32_t*>(p.col[w]);
 
-    // a lane's 16 results per tile all belong to query g * 32 + (lane & 31): fold them, compare once
-    auto reduce = [&](const Acc& acc, int thr, uint32_t g, uint64_t st) {
-        int m = min3i(acc.t[0][0], acc.t[0][1], acc.t[0][2]);
+    // a lane's 16 results per tile all belong to query g * 32 + (lane & 31): fold both tiles (two chains), compare once
+    auto reduce = [&](const Acc& acc, float thr, uint32_t g, uint64_t st) {
+        float m0 = min3f(acc.t[0][0], acc.t[0][1], acc.t[0][2]);
+        float m1 = min3f(acc.t[1][0], acc.t[1][1], acc.t[1][2]);
 #pragma unroll
-        for (int i = 3; i < 15; i += 2) m = min3i(m, acc.t[0][i], acc.t[0][i + 1]);
-        m = min3i(m, acc.t[0][15], acc.t[1][0]);
-#pragma unroll
-        for (int i = 1; i < 15; i += 2) m = min3i(m, acc.t[1][i], acc.t[1][i + 1]);
-        m = min(m, acc.t[1][15]);
-        if (__builtin_expect(m <= thr, 0)) {
+        for (int i = 3; i < 15; i += 2) { m0 = min3f(m0, acc.t[0][i], acc.t[0][i + 1]); m1 = min3f(m1, acc.t[1][i], acc.t[1][i + 1]); }
+        m0 = min3f(m0, acc.t[0][15], acc.t[1][15]);
+        if (__builtin_expect(fminf(m0, m1) <= thr, 0)) {
             // rare: result `reg` of tile t is row (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) of that tile.
             // The step number is laundered so that hipcc does not hoist 32 row numbers per lane out of the group loop
             // (that cost 64 VGPRs in the hot loop for a path taken once in ~10^3 group-steps).
@@ -120,23 +130,27 @@ __global__ __launch_bounds__(BLOCK) void mfma_scan_kernel(const ScanParams p, co
                 for (int reg = 0; reg < 16; ++reg) {
                     if (acc.t[t][reg] <= thr) {
                         const uint64_t row = base + (uint32_t)(t * 32 + (reg & 3) + 8 * (reg >> 2));
-                        if (row <= last_row) emit<MODE>(p, q0 + ql, (uint32_t)(acc.t[t][reg] + pc), row);
+                        if (row <= last_row) emit<MODE>(p, q0 + ql, (uint32_t)((int)acc.t[t][reg] + pc), row);
                     }
                 }
         }
     };
 
-    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v4i a[MT][2 * W];
-    // one word of one group: 2 MFMAs per tile into the group's accumulators
-    auto mm = [&](Acc& acc, int w, const v4i& b0, const v4i& b1) {
+    const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v8i a[MT][W];     // only the first four dwords carry FP4 data; the instruction ignores the rest
+    // one word of one group: one MFMA per tile into the group's accumulators
+    auto mm = [&](Acc& acc, int w, const v4i& b) {
+        const v8i b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < MT; ++t) acc.t[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t][2 * w], b0, w == 0 ? zero : acc.t[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc.t[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t][2 * w + 1], b1, acc.t[t], 0, 0, 0);
+        for (int t = 0; t < MT; ++t)
+            acc.t[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t][w], b8, w == 0 ? zero : acc.t[t], FP4, FP4, 0, SCALE_ONE, 0, SCALE_ONE);
     };
+    // An empty asm naming BOTH accumulator sets right after the first MFMAs of the next group: the fold of the previous
+    // group then depends on it, so hipcc can neither hoist that fold above the MFMAs nor give the two sets the same
+    // registers (it did both in the prototype and serialised MFMA -> s_nop 10 -> fold).
+    auto pin2 = [&](Acc& x, Acc& y) { asm volatile("" : "+v"(x.t[0]), "+v"(x.t[1]), "+v"(y.t[0]), "+v"(y.t[1])); };
     const v4i* lbl = lb + lane;
-    const int* lt = lthr + r;
+    const float* lt = lthr + r;
     auto row_of = [&](uint64_t st, int t) { const uint64_t row = (st * MT + t) * 32 + r; return row <= last_row ? row : last_row; };
 
     uint32_t x[MT][W], xn[MT][W];
@@ -154,26 +168,24 @@ __global__ __launch_bounds__(BLOCK) void mfma_scan_kernel(const ScanParams p, co
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int w = 0; w < W; ++w)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a[t][2 * w + (j >> 2)][j & 3] = (int)spread(x[t][w], j);
+                a[t][w] = v8i{(int)(nibbles(x[t][w], 0) << 1), (int)(nibbles(x[t][w], 1) << 1), (int)(nibbles(x[t][w], 2) << 1),
+                              (int)(nibbles(x[t][w], 3) << 1), 0, 0, 0, 0};                      // bit ? 1.0 (0x2) : 0
 
         // Software pipeline over the (group, word) sequence: two B buffers (one word each) and two accumulator sets.
-        // The fragments of the NEXT word are requested right after the MFMAs of the current one are issued (their buffer
+        // The fragment of the NEXT word is requested right after the MFMAs of the current one are issued (its buffer
         // was consumed one stage earlier), and the results of group g are folded while the MFMAs of group g + 1 run.
-        v4i bx0, bx1, by0, by1;
+        v4i bx = lbl[0], by = lbl[0];
         Acc accX, accY;
-        int thrX = 0, thrY = lt[0];
-        by0 = lbl[0];
-        by1 = lbl[64];
-        // stage(g, w) for group parity P: consume buffer ((P * W + w) & 1), prefetch the next word into the other one
+        float thrX = 0.f, thrY = lt[0];
+        // stage(g, w): consume buffer ((g * W + w) & 1), prefetch the next word into the other one
         auto stage = [&](Acc& acc, uint32_t g, int w, bool y_buf, bool more) {
-            const uint32_t nxt = (g * W + w + 1) * 128;
+            const uint32_t nxt = (g * W + w + 1) * 64;
             if (y_buf) {
-                mm(acc, w, by0, by1);
-                if (more) { bx0 = lbl[nxt]; bx1 = lbl[nxt + 64]; }
+                mm(acc, w, by);
+                if (more) bx = lbl[nxt];
             } else {
-                mm(acc, w, bx0, bx1);
-                if (more) { by0 = lbl[nxt]; by1 = lbl[nxt + 64]; }
+                mm(acc, w, bx);
+                if (more) by = lbl[nxt];
             }
         };
         // group 0
@@ -186,14 +198,14 @@ __global__ __launch_bounds__(BLOCK) void mfma_scan_kernel(const ScanParams p, co
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 stage(accX, g, w, ((W + w) & 1) == 0, true);
-                if (w == 0) reduce(accY, thrY, g - 1, step);
+                if (w == 0) { pin2(accX, accY); reduce(accY, thrY, g - 1, step); }
             }
             // even group g + 1 -> accY; (2 * W + w) & 1 == w & 1
             thrY = lt[(g + 1) * 32];
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 stage(accY, g + 1, w, (w & 1) == 0, true);
-                if (w == 0) reduce(accX, thrX, g, step);
+                if (w == 0) { pin2(accY, accX); reduce(accX, thrX, g, step); }
             }
         }
         // last (odd) group: nothing further to prefetch after its last word
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(BLOCK) void mfma_scan_kernel(const ScanParams p, co
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 stage(accX, g, w, ((W + w) & 1) == 0, w + 1 < W);
-                if (w == 0) reduce(accY, thrY, g - 1, step);
+                if (w == 0) { pin2(accX, accY); reduce(accY, thrY, g - 1, step); }
             }
             reduce(accX, thrX, g, step);
         }
@@ -226,14 +238,14 @@ static int launch_w(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanP
         if (e != hipSuccess) return (int)e;
         attr_set[mi] = true;
     }
-    if (mi == 0) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_COLLECT>), grid, dim3(BLOCK), lds, st, p, groups);
-    else if (mi == 1) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_STRETCH>), grid, dim3(BLOCK), lds, st, p, groups);
-    else hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_BOTH>), grid, dim3(BLOCK), lds, st, p, groups);
+    if (mi == 0) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_COLLECT>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mi == 1) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_STRETCH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_BOTH>), grid, dim3(MBLOCK), lds, st, p, groups);
     return 0;
 }
 
 uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad) {
-    // LDS per group: 32 queries x (64 * W bytes of +1/-1 + thr + popc); keep two blocks per CU (<= 76 KB each)
+    // LDS per group: 32 queries x (32 * W bytes of +1/-1 nibbles + thr + popc); at most 40 KB per block, four blocks per CU
     static const uint32_t max_groups[5] = {0, 32, 16, 10, 8};
     uint32_t need = (nq_pad + 31) / 32;
     need += need & 1;                         // the pipeline walks the groups in pairs
@@ -241,7 +253,15 @@ uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad) {
     return need < max_groups[W] ? need : max_groups[W];
 }
 
-size_t mfma_lds_bytes(int W, uint32_t groups) { return (size_t)groups * (2 * W) * 64 * 16 + (size_t)groups * 32 * 8; }
+size_t mfma_lds_bytes(int W, uint32_t groups) { return (size_t)groups * W * 64 * 16 + (size_t)groups * 32 * 8; }
+
+uint32_t mfma_waves_per_block() { return MBLOCK / 64; }
+
+uint32_t mfma_blocks_per_cu(int W, uint32_t groups) {
+    const uint32_t by_lds = (uint32_t)((160u * 1024u) / mfma_lds_bytes(W, groups));
+    const uint32_t by_regs = W <= 3 ? 3u : 2u;
+    return by_lds < by_regs ? (by_lds ? by_lds : 1u) : by_regs;
+}
 
 int launch_mfma_scan(int W, int mode, uint32_t blocks_x, uint32_t groups, hipStream_t st, const ScanParams& p) {
     const uint32_t chunks = (p.nq_pad + groups * 32 - 1) / (groups * 32);

@@ -31,13 +31,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert out["unit"] == "queries/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert abs(out["value"] - 1024 / (out["ms_per_step"] / 1e3)) / out["value"] < 1e-6
-    assert out["config"]["scan"] == "int8 MFMA"
+    assert out["config"]["scan"] == "FP4 MFMA"
     assert "workload" in out["config"] and "model" not in out["config"]
     roof = out["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_run"):
         assert key in roof, key
     # 1 024-query steps run on the matrix cores by default; whatever the bound, the fraction is a fraction
-    assert roof["bound"] == "mfma" and roof["unit"].startswith("TOP/s") and abs(roof["peak"] - 5033.2) < 1.0
+    assert roof["bound"] == "mfma" and roof["unit"].startswith("TOP/s") and abs(roof["peak"] - 10066.3) < 1.0
     assert roof["traffic_measured_in_run"] is False
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] <= 1.0
     assert roof["launches"] >= 3 and roof["avg_launch_ms"] > 0

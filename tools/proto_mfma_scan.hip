@@ -11,7 +11,7 @@
 // lane-operations per pair.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -o proto_mfma_scan proto_mfma_scan.hip
-// Run  : ./proto_mfma_scan [rows] [queries] [tau] [blocks_per_cu] [tiles per wave step: 1|2] [variant 0|1|2]     (prints ms, pairs/s, check vs a brute-force kernel)
+// Run  : ./proto_mfma_scan [rows] [queries] [tau] [blocks_per_cu] [tiles per wave step: 1|2] [variant 0|1, 3 = FP4] [threads per block]     (prints ms, pairs/s, check vs a brute-force kernel)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -74,8 +74,8 @@ __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b)
 // LDS image: B fragments [G][2][64] v4i (group, mfma, lane) | thr[nq] | popc[nq]
 //   T    row tiles (32 rows each) per wave and step: the B fragments, the threshold and the compare are shared by T tiles
 //   VAR  0 = the real thing; 1 = results not folded (MFMA + LDS floor); 2 = B fragments read once (MFMA + VALU floor)
-template <int GROUPS, int T, int VAR>
-__global__ __launch_bounds__(256) void mfma_scan(const P p) {
+template <int GROUPS, int T, int VAR, int NT>
+__global__ __launch_bounds__(NT) void mfma_scan(const P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v4i* lb = reinterpret_cast<v4i*>(smem);
     int* lthr = reinterpret_cast<int*>(smem + (size_t)GROUPS * 2 * 64 * 16);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void mfma_scan(const P p) {
 
     // prologue: expand the block's queries.  dword d_j = (x >> j) & 0x01010101 holds bits j, j+8, j+16, j+24 of the
     // lane half's 32 bits as bytes 0/1; MFMA (j >> 2) takes it as VGPR (j & 3).  +1/-1: 0x01 | (d * 0xFE).
-    for (uint32_t i = tid; i < (uint32_t)GROUPS * 32 * 2; i += 256) {
+    for (uint32_t i = tid; i < (uint32_t)GROUPS * 32 * 2; i += NT) {
         const uint32_t q = i >> 1, hh = i & 1;
         const uint64_t qw = p.queries[q];
         const uint32_t x = hh ? (uint32_t)(qw >> 32) : (uint32_t)qw;
@@ -104,9 +104,9 @@ __global__ __launch_bounds__(256) void mfma_scan(const P p) {
     __syncthreads();
 
     const uint64_t nsteps = p.n_rows / (32 * T);
-    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    const uint64_t stride = (uint64_t)gridDim.x * (NT / 64);
     const uint32_t* col32 = reinterpret_cast<const uint32_t*>(p.col);
-    uint64_t step = (uint64_t)blockIdx.x * 4 + wave;
+    uint64_t step = (uint64_t)blockIdx.x * (NT / 64) + wave;
     if (step >= nsteps) return;
 
     struct Acc { v16i t[T]; };
@@ -117,15 +117,17 @@ __global__ __launch_bounds__(256) void mfma_scan(const P p) {
             m = acc.t[0][0];
             if constexpr (T == 2) m = min(m, acc.t[1][0]);
         } else {
+            // two independent chains (one per tile) instead of one 17-deep dependent chain
             m = min3i(acc.t[0][0], acc.t[0][1], acc.t[0][2]);
-#pragma unroll
-            for (int i = 3; i < 15; i += 2) m = min3i(m, acc.t[0][i], acc.t[0][i + 1]);
             if constexpr (T == 2) {
-                m = min3i(m, acc.t[0][15], acc.t[1][0]);
+                int m1 = min3i(acc.t[1][0], acc.t[1][1], acc.t[1][2]);
 #pragma unroll
-                for (int i = 1; i < 15; i += 2) m = min3i(m, acc.t[1][i], acc.t[1][i + 1]);
-                m = min(m, acc.t[1][15]);
+                for (int i = 3; i < 15; i += 2) { m = min3i(m, acc.t[0][i], acc.t[0][i + 1]); m1 = min3i(m1, acc.t[1][i], acc.t[1][i + 1]); }
+                m = min3i(m, acc.t[0][15], acc.t[1][15]);
+                m = min(m, m1);
             } else {
+#pragma unroll
+                for (int i = 3; i < 15; i += 2) m = min3i(m, acc.t[0][i], acc.t[0][i + 1]);
                 m = min(m, acc.t[0][15]);
             }
         }
@@ -133,12 +135,15 @@ __global__ __launch_bounds__(256) void mfma_scan(const P p) {
             // rare: row of result `reg` = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), query = g * 32 + (lane & 31)
             const uint32_t q = g * 32 + r;
             const int pc = lpop[q];
+            uint32_t st_lo = (uint32_t)st, st_hi = (uint32_t)(st >> 32);
+            asm volatile("" : "+v"(st_lo), "+v"(st_hi));        // keeps hipcc from hoisting 32 row numbers per lane out of the group loop
+            const uint64_t base = (((uint64_t)st_hi << 32) | st_lo) * (32 * T) + 4 * h;
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     if (acc.t[t][reg] <= thr) {
-                        const uint64_t row = (st * T + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const uint64_t row = base + (uint32_t)(t * 32 + (reg & 3) + 8 * (reg >> 2));
                         const uint32_t hd = (uint32_t)(acc.t[t][reg] + pc);
                         const uint32_t slot = atomicAdd(&p.cnt[q], 1u);
                         if (slot < p.cap) p.cand[(uint64_t)q * p.cap + slot] = ((uint64_t)hd << 48) | row;
@@ -197,6 +202,131 @@ __global__ __launch_bounds__(256) void mfma_scan(const P p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// FP4 variant: v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands (0x2 = +1, 0xA = -1, 0x0 = 0; both scales 2^0) takes
+// the whole 64-bit code in ONE instruction: 4 VGPRs of A (32 bits of a row -> 32 nibbles per lane), 4 VGPRs of B, f32
+// results (exact: |dot| <= 64).  LDS image: B fragments [G][64] v4i | thr[nq] (float) | popc[nq].
+// ------------------------------------------------------------------------------------------------------------------
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+// dword j (0..3) of a 32-bit half: nibble t holds bit j + 4 t as 0x2 (e2m1 1.0) or 0x0
+__device__ __forceinline__ uint32_t nib(uint32_t x, int j) { return ((x >> j) & 0x11111111u) << 1; }
+
+template <int GROUPS, int T, int NT>
+__global__ __launch_bounds__(NT) void mfma_scan_fp4(const P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v4i* lb = reinterpret_cast<v4i*>(smem);
+    float* lthr = reinterpret_cast<float*>(smem + (size_t)GROUPS * 64 * 16);
+    int* lpop = reinterpret_cast<int*>(lthr + GROUPS * 32);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    for (uint32_t i = tid; i < (uint32_t)GROUPS * 32 * 2; i += NT) {
+        const uint32_t q = i >> 1, hh = i & 1;
+        const uint64_t qw = p.queries[q];
+        const uint32_t x = hh ? (uint32_t)(qw >> 32) : (uint32_t)qw;
+        const uint32_t g = q >> 5, c = q & 31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            reinterpret_cast<uint32_t*>(&lb[(size_t)g * 64 + hh * 32 + c])[j] = 0x22222222u | (((x >> j) & 0x11111111u) << 3);    // bit ? -1 : +1
+        if (hh == 0) {
+            const int pc = __popcll(qw);
+            lpop[q] = pc;
+            lthr[q] = (float)(p.tau[q] - pc);
+        }
+    }
+    __syncthreads();
+    const uint64_t nsteps = p.n_rows / (32 * T);
+    const uint64_t stride = (uint64_t)gridDim.x * (NT / 64);
+    const uint32_t* col32 = reinterpret_cast<const uint32_t*>(p.col);
+    uint64_t step = (uint64_t)blockIdx.x * (NT / 64) + wave;
+    if (step >= nsteps) return;
+    struct Acc { v16f t[T]; };
+    auto reduce = [&](const Acc& acc, float thr, int g, uint64_t st) {
+        float m = min3f(acc.t[0][0], acc.t[0][1], acc.t[0][2]);
+        if constexpr (T == 2) {
+            float m1 = min3f(acc.t[1][0], acc.t[1][1], acc.t[1][2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) { m = min3f(m, acc.t[0][i], acc.t[0][i + 1]); m1 = min3f(m1, acc.t[1][i], acc.t[1][i + 1]); }
+            m = min3f(m, acc.t[0][15], acc.t[1][15]);
+            m = fminf(m, m1);
+        } else {
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) m = min3f(m, acc.t[0][i], acc.t[0][i + 1]);
+            m = fminf(m, acc.t[0][15]);
+        }
+        if (__builtin_expect(m <= thr, 0)) {
+            const uint32_t q = g * 32 + r;
+            const int pc = lpop[q];
+            uint32_t st_lo = (uint32_t)st, st_hi = (uint32_t)(st >> 32);
+            asm volatile("" : "+v"(st_lo), "+v"(st_hi));
+            const uint64_t base = (((uint64_t)st_hi << 32) | st_lo) * (32 * T) + 4 * h;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (acc.t[t][reg] <= thr) {
+                        const uint64_t row = base + (uint32_t)(t * 32 + (reg & 3) + 8 * (reg >> 2));
+                        const uint32_t hd = (uint32_t)((int)acc.t[t][reg] + pc);
+                        const uint32_t slot = atomicAdd(&p.cnt[q], 1u);
+                        if (slot < p.cap) p.cand[(uint64_t)q * p.cap + slot] = ((uint64_t)hd << 48) | row;
+                    }
+                }
+        }
+    };
+    const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v8i a[T];
+    auto mm = [&](Acc& acc, const v4i& b) {
+        const v8i b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc.t[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t], b8, zero, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    };
+    const v4i* lbl = lb + lane;
+    const float* lt = lthr + r;
+    uint32_t x[T], xn[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) x[t] = col32[((step * T + t) * 32 + r) * 2 + h];
+    for (; step < nsteps; step += stride) {
+        const uint64_t ns = step + stride < nsteps ? step + stride : step;
+#pragma unroll
+        for (int t = 0; t < T; ++t) xn[t] = col32[((ns * T + t) * 32 + r) * 2 + h];
+#pragma unroll
+        for (int t = 0; t < T; ++t) a[t] = v8i{(int)nib(x[t], 0), (int)nib(x[t], 1), (int)nib(x[t], 2), (int)nib(x[t], 3), 0, 0, 0, 0};
+        v4i by = lbl[0], bx = lbl[64];
+        float thrY = lt[0], thrX = lt[32];
+        Acc accY, accX;
+        mm(accY, by);
+        // An empty asm naming BOTH accumulator sets right after the MFMAs of the next group: the fold below then depends
+        // on it, so hipcc can neither hoist the fold above those MFMAs nor give the two sets the same registers (it did
+        // both, and serialised MFMA -> s_nop 10 -> fold).
+        auto pin2 = [&](Acc& a0, Acc& a1) {
+            if constexpr (T == 2) asm volatile("" : "+v"(a0.t[0]), "+v"(a0.t[1]), "+v"(a1.t[0]), "+v"(a1.t[1]));
+            else asm volatile("" : "+v"(a0.t[0]), "+v"(a1.t[0]));
+        };
+#pragma unroll 1
+        for (int g = 0; g < GROUPS - 2; g += 2) {
+            mm(accX, bx);
+            pin2(accX, accY);
+            by = lbl[(g + 2) * 64];
+            const float thrYn = lt[(g + 2) * 32];
+            reduce(accY, thrY, g, step);
+            thrY = thrYn;
+            mm(accY, by);
+            pin2(accY, accX);
+            bx = lbl[(g + 3) * 64];
+            const float thrXn = lt[(g + 3) * 32];
+            reduce(accX, thrX, g + 1, step);
+            thrX = thrXn;
+        }
+        mm(accX, bx);
+        reduce(accY, thrY, GROUPS - 2, step);
+        reduce(accX, thrX, GROUPS - 1, step);
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[t] = xn[t];
+    }
+}
+
+
 int main(int argc, char** argv) {
     const uint64_t rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 16ull << 20;
     const uint32_t nq = argc > 2 ? atoi(argv[2]) : 1024;
@@ -227,11 +357,18 @@ int main(int argc, char** argv) {
     const int groups = nq / 32;
     const size_t lds = (size_t)groups * 2 * 64 * 16 + (size_t)nq * 8;
     p.n_rows = rows / 64 * 64;
-#define LAUNCH_CASE(TT, VV) if (T == TT && var == VV) { static bool once = false; if (!once) { once = true; \
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<32, TT, VV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); } \
-        hipLaunchKernelGGL((mfma_scan<32, TT, VV>), dim3(cus * bpc), dim3(256), lds, 0, p); }
+    const int nt = argc > 7 ? atoi(argv[7]) : 256;
+#define LAUNCH_CASE(TT, VV, NTT) if (T == TT && var == VV && nt == NTT) { static bool once = false; if (!once) { once = true; \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan<32, TT, VV, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); } \
+        hipLaunchKernelGGL((mfma_scan<32, TT, VV, NTT>), dim3(cus * bpc), dim3(NTT), lds, 0, p); }
+    const size_t lds4 = (size_t)groups * 64 * 16 + (size_t)nq * 8;
+#define LAUNCH_FP4(TT, NTT) if (T == TT && var == 3 && nt == NTT) { static bool once = false; if (!once) { once = true; \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_scan_fp4<32, TT, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); } \
+        hipLaunchKernelGGL((mfma_scan_fp4<32, TT, NTT>), dim3(cus * bpc), dim3(NTT), lds4, 0, p); }
     auto launch = [&]() {
-        LAUNCH_CASE(1, 0) LAUNCH_CASE(1, 1) LAUNCH_CASE(1, 2) LAUNCH_CASE(2, 0) LAUNCH_CASE(2, 1) LAUNCH_CASE(2, 2)
+        LAUNCH_FP4(1, 256) LAUNCH_FP4(2, 256) LAUNCH_FP4(1, 512) LAUNCH_FP4(2, 512)
+        LAUNCH_CASE(1, 0, 256) LAUNCH_CASE(1, 1, 256) LAUNCH_CASE(2, 0, 256) LAUNCH_CASE(2, 1, 256)
+        LAUNCH_CASE(1, 0, 512) LAUNCH_CASE(2, 0, 384) LAUNCH_CASE(2, 0, 512) LAUNCH_CASE(1, 0, 1024) LAUNCH_CASE(2, 0, 768) LAUNCH_CASE(1, 0, 768)
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -252,8 +389,8 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double pairs = (double)p.n_rows * nq;
-    printf("mfma_scan T=%d var=%d: rows=%llu queries=%u tau=%d blocks/CU=%d lds=%zu B : %.3f ms  %.3e pairs/s  (%.1f cycles@2.4GHz per 1024 pairs per SIMD)  %.2f PB/s int8-ops of 5.03\n",
-           T, var, (unsigned long long)p.n_rows, nq, tau, bpc, lds, best, pairs / (best * 1e-3),
+    printf("mfma_scan T=%d var=%d threads=%d: rows=%llu queries=%u tau=%d blocks/CU=%d lds=%zu B : %.3f ms  %.3e pairs/s  (%.1f cycles@2.4GHz per 1024 pairs per SIMD)  %.2f PB/s int8-ops of 5.03\n",
+           T, var, nt, (unsigned long long)p.n_rows, nq, tau, bpc, lds, best, pairs / (best * 1e-3),
            best * 1e-3 * 2.4e9 / (pairs / 1024 / (cus * 4.0)), pairs * 128 / (best * 1e-3) / 1e15);
     // check against brute force
     std::vector<uint32_t> c1(nq), c2(nq);
