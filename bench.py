@@ -15,7 +15,7 @@ Prints ONE JSON line on rank 0.
 
 `roofline` describes the dominant kernel of the TIMED steps, measured with HIP events on the library's own stream
 inside the timed region:
-  * batches of >= 32 queries run the collect scan on the matrix cores in FP4 (csrc/mfma_scan.hip): bound "mfma",
+  * batches of > 16 queries run the collect scan on the matrix cores in FP4 (csrc/mfma_scan.hip): bound "mfma",
     achieved = (rows x queries x 64-bit words) x 128 operations / launch time, peak = dense FP4 MFMA rate;
   * with `--opt mfma=0` the XOR + popcount kernel runs: cache-blocked it is bound by VALU issue (bound "valu",
     in (row, query, word) triples per second against the measured issue rates of v_xor / v_bcnt / v_min3), and with
@@ -204,7 +204,7 @@ def main():
     words = (args.nbytes + 7) // 8
     engine = HipEngine(local_rank)
     engine.set_option("queries_per_pass", args.tq)
-    opts = {"mfma": 1, "stretch_mb": 128, "mfma_min_queries": 32}
+    opts = {"mfma": 1, "stretch_mb": 128, "mfma_min_queries": 17}
     for kv in args.opt:
         name, _, val = kv.partition("=")
         engine.set_option(name, int(val))

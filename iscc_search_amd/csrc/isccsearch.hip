@@ -159,10 +159,10 @@ struct isccsearch_handle {
     uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
     // large batches: the scan as an FP4 matrix-core contraction (mfma_scan.hip) instead of XOR + popcount on the VALU
     bool mfma = true;
-    uint32_t mfma_min_queries = 32;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
-                                      // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms; 16 queries cost the same 0.49 ms against ~0.3 ms)
+    uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
+                                      // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
-    uint64_t mfma_level_growth = 8;   // threshold levels when the scan runs on the matrix cores (k <= 64)
+    uint64_t mfma_level_growth = 4;   // threshold levels when the scan runs on the matrix cores (k <= 64): 4 / 6 / 8 measured 295.5 / 295.9 / 290.4 k q/s at 100 M rows and 1.35 / 1.28 / 1.27 M at 12.5 M
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
     // scratch

@@ -1,7 +1,7 @@
 """
 The matrix-core (FP4 MFMA) form of the scan (``csrc/mfma_scan.hip``) against the oracle.
 
-By default the engine sends a launch to the matrix cores only for batches of >= 32 queries over >= 65 536 rows, which
+By default the engine sends a launch to the matrix cores only for batches of > 16 queries over >= 65 536 rows, which
 most parity cases are too small to reach.  Here the thresholds are dropped to 1 query / 1 row so that EVERY scan launch
 of the re-run parity, range-limited, fuzz and search_many cases takes that path (all code lengths 1..32 bytes, masked
 prefixes, mixed-length NPHD segments, 64- and 128-bit keys, tails that are not a multiple of 64 rows, overflow
@@ -29,7 +29,7 @@ def forced(hip_engine):
     before = hip_engine.stats()["mfma_launches"]
     yield hip_engine
     ran = hip_engine.stats()["mfma_launches"] - before
-    hip_engine.set_option("mfma_min_queries", 32)
+    hip_engine.set_option("mfma_min_queries", 17)
     hip_engine.set_option("mfma_min_rows", 65536)
     assert ran > 0, "the case never reached the MFMA kernel"
 

@@ -27,6 +27,8 @@ def timeit(fn, reps=10, warm=2):
 def main():
     what = set(sys.argv[1:]) or {"latency", "small", "simprint", "mixed", "threads", "within"}
     eng = HipEngine(0)
+    for item in filter(None, os.environ.get("ISCC_HIP_OPTS", "").split(",")):      # e.g. ISCC_HIP_OPTS=mfma=0
+        eng.set_option(item.split("=")[0].strip(), int(item.split("=")[1]))
     rng = np.random.default_rng(0)
     if "latency" in what:
         t = eng.open_table(_lib.METRIC_HAMMING, 1, 8)

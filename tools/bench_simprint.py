@@ -13,6 +13,8 @@ from iscc_search_amd.engine import HipEngine  # noqa: E402
 from iscc_search_amd.simprint import HipSimprintIndex, pack_chunk_pointer  # noqa: E402
 
 eng = HipEngine(0)
+for _item in filter(None, os.environ.get("ISCC_HIP_OPTS", "").split(",")):      # e.g. ISCC_HIP_OPTS=mfma=0
+    eng.set_option(_item.split("=")[0].strip(), int(_item.split("=")[1]))
 rng = np.random.default_rng(0)
 n_assets, chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000, 40      # 4 M chunks
 ndim = 128
