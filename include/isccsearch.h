@@ -214,6 +214,26 @@ int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq,
                             const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
                             uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
 
+/* The same two steps WITHOUT host round-trips in between (one synchronisation per multi-GPU search step instead of four):
+ *   search_device_async   enqueues the search on the library's stream and makes `consumer_stream` (a hipStream_t, e.g. the
+ *                         stream the all-gather is issued on) wait for it; it does not wait itself.  max_hamming < 0 = plain
+ *                         top-k.  A query whose candidate list overflowed cannot take the exact fallback without the host,
+ *                         so its count is written as ISCCSEARCH_COUNT_OVERFLOW; merge_kernel propagates the marker and the
+ *                         caller re-runs the step through the synchronous entry points (rare; every rank sees the same
+ *                         merged counts, so all ranks take the same decision).  Tables with several segments and batches
+ *                         beyond 1 024 queries run the synchronous path inside the call.
+ *   merge_device_after    as merge_device, ordered after everything queued on `producer_stream` (the stream the gathered
+ *                         blocks were produced on); ONE device->host copy and ONE synchronisation.  out_count[q] ==
+ *                         ISCCSEARCH_COUNT_OVERFLOW reports the marker. */
+#define ISCCSEARCH_COUNT_OVERFLOW 0xFFFFFFFFu
+int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                                   const uint8_t* q_nbytes, uint32_t k, int32_t max_hamming,
+                                   void* d_records, uint32_t* d_counts, void* consumer_stream);
+int isccsearch_merge_device_after(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
+                                  const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
+                                  void* producer_stream,
+                                  uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ METRIC_HAMMING = 0
 METRIC_NPHD = 1
 MAX_BYTES = 32
 MAX_K = 4096
+COUNT_OVERFLOW = 0xFFFFFFFF   # ISCCSEARCH_COUNT_OVERFLOW: a count the asynchronous device search could not complete
 ADD_TRUSTED_UNIQUE = 1
 
 # every symbol include/isccsearch.h declares
@@ -28,6 +29,7 @@ EXPORTS = (
     "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
     "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_search_many", "isccsearch_doc_freq", "isccsearch_get_freq",
     "isccsearch_search_device", "isccsearch_search_within_device", "isccsearch_merge_device",
+    "isccsearch_search_device_async", "isccsearch_merge_device_after",
 )
 
 RECORD_DTYPE = np.dtype(
@@ -136,6 +138,8 @@ def load_library():
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
         "isccsearch_search_within_device": (i, [vp, u32, u32, u64p, u8p, u32, u32, vp, vp]),
         "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, u64p, u32p, u16p, u32p]),
+        "isccsearch_search_device_async": (i, [vp, u32, u32, u64p, u8p, u32, ctypes.c_int32, vp, vp, vp]),
+        "isccsearch_merge_device_after": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, vp, u64p, u32p, u16p, u32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -180,6 +180,9 @@ struct isccsearch_handle {
     std::vector<isk::Record> h_final;
     std::vector<uint32_t> h_cnt, h_overflow;
     // profiling
+    // asynchronous device searches: "results ready" for the consumer stream, "query upload done" for the pinned staging
+    hipEvent_t ev_done = nullptr, ev_staged = nullptr, ev_producer = nullptr;
+    bool ev_staged_pending = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     isccsearch_stats stats{};
@@ -395,6 +398,7 @@ struct Batch {
     uint32_t nq_pad = 0, groups = 0, cap = 0, P = 0;
     size_t sel_lds = 0;
     bool multi = false;
+    bool mark_overflow = false;         // search_device_async: overflowed queries report COUNT_OVERFLOW instead of being fixed here
     std::vector<Job> jobs;
 
     Batch(H* h_, Table& t_, uint32_t nq_, uint32_t qbytes_, uint32_t k_, isk::Record* out, uint32_t* out_cnt)
@@ -415,6 +419,7 @@ struct Batch {
         c.sl.out_count = multi ? h->d_listcnt.p + ji * (size_t)nq : d_out_cnt;
         c.sl.overflow = d_flags + ji * (size_t)nq_pad;
         c.sl.k = k; c.sl.P = P; c.sl.prefix_bits = j.pbytes * 8; c.sl.q_base = 0;
+        c.sl.overflow_count = mark_overflow ? isk::COUNT_OVERFLOW : 0;
         return c;
     }
     void launch_select(const isk::SelectParams& sl, uint32_t blocks) const {
@@ -488,10 +493,13 @@ struct Batch {
         // stage queries through pinned memory: [nq_pad][4], padded words zero
         if ((rc = h->p_queries.ensure(pq_off + (size_t)nq_pad * 4))) return rc;   // (no-op when the caller pre-sized it)
         uint64_t* const pq = h->p_queries.p + pq_off;
+        // an asynchronous caller may come back before the previous batch's query upload has left the pinned staging buffer
+        if (h->ev_staged_pending) { HIPOK(hipEventSynchronize(h->ev_staged)); h->ev_staged_pending = false; }
         memset(pq, 0, (size_t)nq_pad * 4 * 8);
         for (uint32_t q = 0; q < nq; ++q)
             for (int w = 0; w < t.max_words; ++w) pq[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
         HIPOK(hipMemcpyAsync(h->d_queries.p, pq, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
+        if (mark_overflow) { HIPOK(hipEventRecord(h->ev_staged, h->stream)); h->ev_staged_pending = true; }
 
         for (size_t ji = 0; ji < jobs.size(); ++ji) {
             const Job& j = jobs[ji];
@@ -741,8 +749,8 @@ void unpack_records(const isk::Record* rec, const uint32_t* cnt, uint32_t nq, ui
                     uint64_t* out_keys, uint32_t* out_h, uint16_t* out_p, uint32_t* out_c) {
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t dq = dest_index ? dest_index[q] : q;
-        const uint32_t c = std::min(cnt[q], k);
-        out_c[dq] = c;
+        const uint32_t c = cnt[q] == isk::COUNT_OVERFLOW ? 0 : std::min(cnt[q], k);
+        out_c[dq] = cnt[q] == isk::COUNT_OVERFLOW ? isk::COUNT_OVERFLOW : c;
         for (uint32_t i = 0; i < k; ++i) {
             const size_t o = (size_t)dq * k + i;
             if (i < c) {
@@ -799,6 +807,9 @@ int isccsearch_create(int device_id, isccsearch_handle** out) {
     h->device = device_id;
     h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPOK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPOK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    HIPOK(hipEventCreateWithFlags(&h->ev_staged, hipEventDisableTiming));
+    HIPOK(hipEventCreateWithFlags(&h->ev_producer, hipEventDisableTiming));
     std::vector<uint16_t> rank;
     build_rank_table(rank);
     HIPOK(hipMalloc((void**)&h->d_rank, rank.size() * sizeof(uint16_t)));
@@ -828,6 +839,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         h->d_block.release(); h->p_block.release();
         if (h->d_rank) (void)hipFree(h->d_rank);
         for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (hipEvent_t e : {h->ev_done, h->ev_staged, h->ev_producer}) if (e) (void)hipEventDestroy(e);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -1701,9 +1713,10 @@ int isccsearch_search_within_device(isccsearch_handle* h, uint32_t table, uint32
     return search_device_impl(h, table, nq, q_words, q_nbytes, k, (int)max_hamming, d_records, d_counts);
 }
 
-int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
-                            const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
-                            uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+static int merge_device_impl(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
+                             const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
+                             void* producer_stream, bool ordered,
+                             uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
     if (!h) return fail(-EINVAL, "handle is NULL");
     if (nq == 0) return 0;
     if (n_lists < 1 || k < 1 || k > ISCCSEARCH_MAX_K || (key_words != 1 && key_words != 2)) return fail(-EINVAL, "bad arguments");
@@ -1714,17 +1727,78 @@ int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq,
     if ((rc = h->d_final.ensure((size_t)nq * k))) return rc;
     if ((rc = h->d_outcnt.ensure(nq))) return rc;
     if (list_stride % 8 || count_stride % 4 || (uintptr_t)d_records % 8 || (uintptr_t)d_counts % 4) return fail(-EINVAL, "misaligned record/count blocks");
+    if (ordered) {
+        // the gathered blocks are produced on the caller's stream: order the merge behind it without a host round-trip
+        HIPOK(hipEventRecord(h->ev_producer, static_cast<hipStream_t>(producer_stream)));
+        HIPOK(hipStreamWaitEvent(h->stream, h->ev_producer, 0));
+    }
     isk::MergeParams mp{static_cast<const unsigned char*>(d_records), static_cast<const unsigned char*>(d_counts),
                         list_stride, count_stride, h->d_final.p, h->d_outcnt.p, n_lists, nq, k};
     hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
     HIPOK(hipGetLastError());
-    h->h_final.resize((size_t)nq * k);
-    h->h_cnt.resize(nq);
-    HIPOK(hipMemcpyAsync(h->h_final.data(), h->d_final.p, (size_t)nq * k * sizeof(isk::Record), hipMemcpyDeviceToHost, h->stream));
-    HIPOK(hipMemcpyAsync(h->h_cnt.data(), h->d_outcnt.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    // ONE pinned block {records | counts}: a single device->host copy and a single synchronisation
+    const size_t rec_bytes = (size_t)nq * k * sizeof(isk::Record);
+    if ((rc = h->p_block.ensure(rec_bytes + (size_t)nq * sizeof(uint32_t)))) return rc;
+    HIPOK(hipMemcpyAsync(h->p_block.p, h->d_final.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipMemcpyAsync(h->p_block.p + rec_bytes, h->d_outcnt.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPOK(hipStreamSynchronize(h->stream));
-    unpack_records(h->h_final.data(), h->h_cnt.data(), nq, k, key_words, nullptr, out_keys, out_hamming, out_prefix_bits, out_count);
+    unpack_records(reinterpret_cast<const isk::Record*>(h->p_block.p), reinterpret_cast<const uint32_t*>(h->p_block.p + rec_bytes), nq, k, key_words,
+                   nullptr, out_keys, out_hamming, out_prefix_bits, out_count);
     return 0;
+}
+
+int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
+                            const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
+                            uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+    return merge_device_impl(h, n_lists, nq, k, key_words, d_records, d_counts, list_stride, count_stride, nullptr, false,
+                             out_keys, out_hamming, out_prefix_bits, out_count);
+}
+
+int isccsearch_merge_device_after(isccsearch_handle* h, uint32_t n_lists, uint32_t nq, uint32_t k, int key_words,
+                                  const void* d_records, const void* d_counts, uint64_t list_stride, uint64_t count_stride,
+                                  void* producer_stream,
+                                  uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count) {
+    return merge_device_impl(h, n_lists, nq, k, key_words, d_records, d_counts, list_stride, count_stride, producer_stream, true,
+                             out_keys, out_hamming, out_prefix_bits, out_count);
+}
+
+int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                                   const uint8_t* q_nbytes, uint32_t k, int32_t max_hamming,
+                                   void* d_records, uint32_t* d_counts, void* consumer_stream) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (max_hamming > 256) return fail(-EINVAL, "max_hamming %d exceeds 256", max_hamming);
+    const int radius = max_hamming < 0 ? -1 : max_hamming;
+    bool async = nq > 0 && nq <= QB_MAX && k >= 1 && k <= ISCCSEARCH_MAX_K && q_words && d_records && d_counts;
+    if (async) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        Table* tp;
+        int rc = get_table(h, table, tp);
+        if (rc) return rc;
+        Table& t = *tp;
+        if ((rc = check_query_lengths(t, nq, q_nbytes))) return rc;
+        uint32_t len = (uint32_t)t.max_bytes, segments = 0;
+        for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) segments += t.seg[b].n ? 1 : 0;
+        if (t.metric == ISCCSEARCH_METRIC_NPHD) {
+            len = q_nbytes[0];
+            for (uint32_t q = 1; q < nq; ++q)
+                if (q_nbytes[q] != len) return fail(-EINVAL, "search_device needs queries of one byte length (query %u differs)", q);
+        }
+        if (segments <= 1) {
+            HIPOK(hipSetDevice(h->device));
+            h->stats.searches += 1;
+            h->stats.queries += nq;
+            Batch batch(h, t, nq, len, k, static_cast<isk::Record*>(d_records), d_counts);
+            batch.radius = radius;
+            batch.mark_overflow = true;
+            if ((rc = batch.begin(q_words))) return rc;
+            HIPOK(hipEventRecord(h->ev_done, h->stream));
+            HIPOK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->ev_done, 0));
+            return 0;
+        }
+    }
+    // several segments (their lists must be fixed and merged with the host's help), oversized batches, bad arguments: the
+    // synchronous path does the work and the reporting; the results are complete when it returns
+    return search_device_impl(h, table, nq, q_words, q_nbytes, k, radius, d_records, d_counts);
 }
 
 }  // extern "C"

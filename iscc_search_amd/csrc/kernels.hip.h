@@ -612,6 +612,8 @@ struct SelectParams {
     uint32_t P;               // power of two >= min(k, cap)
     uint32_t prefix_bits;
     uint32_t q_base;          // block b serves query q_base + b
+    uint32_t overflow_count;  // what out_count[q] becomes when the candidate list overflowed: 0, or COUNT_OVERFLOW for callers
+                              // that cannot look at the flags before the results travel on (search_device_async)
 };
 
 template <int KW>
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
     const uint32_t total = p.cnt[(uint64_t)q * CNT_STRIDE];
     if (tid == 0) p.overflow[q] = total > p.cap ? 1u : 0u;   // always written: the host never has to clear the flags
     if (total > p.cap) {             // candidate list overflowed: host reruns this query exactly
-        if (tid == 0) p.out_count[q] = 0;
+        if (tid == 0) p.out_count[q] = p.overflow_count;
         return;
     }
     const uint64_t* cand = p.cand + (uint64_t)q * p.cap;
@@ -886,12 +888,19 @@ __device__ __forceinline__ bool rec_less(const Record& a, const Record& b) {
 __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams p) {
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     auto list_of = [&](uint32_t l) { return reinterpret_cast<const Record*>(p.lists + (uint64_t)l * p.list_stride) + (uint64_t)q * p.k; };
+    auto raw_count = [&](uint32_t l) { return reinterpret_cast<const uint32_t*>(p.counts + (uint64_t)l * p.count_stride)[q]; };
     auto count_of = [&](uint32_t l) {
-        const uint32_t c = reinterpret_cast<const uint32_t*>(p.counts + (uint64_t)l * p.count_stride)[q];
+        const uint32_t c = raw_count(l);
         return c < p.k ? c : p.k;
     };
     uint32_t total = 0;
-    for (uint32_t l = 0; l < p.n_lists; ++l) total += count_of(l);
+    for (uint32_t l = 0; l < p.n_lists; ++l) {
+        if (raw_count(l) == COUNT_OVERFLOW) {      // a list that could not be completed without the host: pass the marker on
+            if (tid == 0) p.out_count[q] = COUNT_OVERFLOW;
+            return;
+        }
+        total += count_of(l);
+    }
     const uint32_t keff = total < p.k ? total : p.k;
     for (uint32_t e = tid; e < p.n_lists * p.k; e += BLOCK) {
         const uint32_t l = e / p.k, i = e % p.k;

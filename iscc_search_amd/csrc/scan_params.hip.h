@@ -14,6 +14,7 @@ constexpr uint32_t CNT_STRIDE = 32;   // one candidate counter per 128-byte line
                                       // words of one line serialise at the memory side (~90 M/s per line)
 constexpr uint32_t BIT31 = 0x80000000u;
 constexpr uint32_t BIAS_NEVER = 0x80000000u;  // bias + h always has bit 31 set: never a candidate
+constexpr uint32_t COUNT_OVERFLOW = 0xFFFFFFFFu;   // == ISCCSEARCH_COUNT_OVERFLOW: "this list needs the exact fallback"
 constexpr int MODE_COLLECT = 0;   // append candidates
 constexpr int MODE_HIST = 1;      // count candidates per hamming distance
 constexpr int MODE_BOTH = 2;      // both: the threshold levels

@@ -86,18 +86,21 @@ class HipEngine:
         _lib.check(self._lib.isccsearch_stats_get(self.handle, ctypes.byref(st), 1 if reset else 0))
         return st.as_dict()
 
-    def merge_device(self, n_lists, nq, k, key_words, d_records_ptr, d_counts_ptr, list_stride, count_stride):
-        # type: (int, int, int, int, int, int, int, int) -> tuple
-        """k-way merge of per-shard result blocks held in device memory (``isccsearch_merge_device``)."""
+    def merge_device(self, n_lists, nq, k, key_words, d_records_ptr, d_counts_ptr, list_stride, count_stride, after_stream=None):
+        # type: (int, int, int, int, int, int, int, int, int | None) -> tuple
+        """
+        k-way merge of per-shard result blocks held in device memory (``isccsearch_merge_device``).  With ``after_stream``
+        (a HIP stream handle) the merge is ordered behind that stream on the device instead of by a host synchronisation
+        (``isccsearch_merge_device_after``); a count of ``_lib.COUNT_OVERFLOW`` then marks a query some shard could not
+        complete asynchronously.
+        """
         out = _alloc_out(nq, k, key_words)
-        _lib.check(
-            self._lib.isccsearch_merge_device(
-                self.handle, n_lists, nq, k, key_words, ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr),
-                list_stride, count_stride,
-                _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32),
-                _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32),
-            )
-        )
+        outs = (_lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32), _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32))
+        args = (self.handle, n_lists, nq, k, key_words, ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr), list_stride, count_stride)
+        if after_stream is None:
+            _lib.check(self._lib.isccsearch_merge_device(*args, *outs))
+        else:
+            _lib.check(self._lib.isccsearch_merge_device_after(*args, ctypes.c_void_p(after_stream), *outs))
         return out
 
     def search_many(self, requests):
@@ -349,14 +352,21 @@ class HipTable:
                 self.engine.handle, self.id, n, _lib.ptr(keys, ctypes.c_uint64), int(dup_limit), _lib.ptr(out, ctypes.c_uint32)))
         return out
 
-    def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr, max_hamming=None):
-        # type: (np.ndarray, np.ndarray | None, int, int, int, int | None) -> None
-        """Same search (range-limited when ``max_hamming`` is given), results left in caller-owned device memory."""
+    def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr, max_hamming=None, consumer_stream=None):
+        # type: (np.ndarray, np.ndarray | None, int, int, int, int | None, int | None) -> None
+        """
+        Same search (range-limited when ``max_hamming`` is given), results left in caller-owned device memory.  With
+        ``consumer_stream`` (a HIP stream handle) the call does not wait for the GPU: that stream is made to wait for the
+        results instead, and overflowed queries come back with a count of ``_lib.COUNT_OVERFLOW`` (``isccsearch_search_device_async``).
+        """
         q_words = self._words(q_words)
         nq = q_words.shape[0]
         q_nbytes = self._nbytes(q_nbytes, nq)
         lib, args = self.engine._lib, (self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k)
         out = (ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr))
+        if consumer_stream is not None:
+            _lib.check(lib.isccsearch_search_device_async(*args, -1 if max_hamming is None else int(max_hamming), *out, ctypes.c_void_p(consumer_stream)))
+            return
         if max_hamming is None:
             _lib.check(lib.isccsearch_search_device(*args, *out))
         else:

@@ -16,6 +16,7 @@ C-ABI); tests drive the same class over gloo with an oracle-backed ops object.
 import numpy as np
 
 RECORD_BYTES = 24
+COUNT_OVERFLOW = 0xFFFFFFFF   # _lib.COUNT_OVERFLOW (kept here so that this module imports without the HIP library)
 
 
 def shard_range(n_rows, rank, world_size):
@@ -52,22 +53,30 @@ class HipShardOps:
         self.device = torch.device(device)
         self.key_words = table.key_words
 
-    def local_search(self, q_words, q_nbytes, k, max_hamming=None):
-        """One device block {records | counts} holding this shard's exact top-k (within ``max_hamming`` if given)."""
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def local_search(self, q_words, q_nbytes, k, max_hamming=None, synchronous=False):
+        """
+        One device block {records | counts} holding this shard's exact top-k (within ``max_hamming`` if given).
+
+        Asynchronous by default: the search is queued on the library's stream and torch's current stream -- the one the
+        all-gather is issued on -- waits for it on the device; nothing waits on the host.  ``synchronous`` runs the
+        classic path, which also completes queries whose candidate list overflowed (the asynchronous one marks them).
+        """
         torch = self.torch
         nq = q_words.shape[0]
         rec_bytes, blk = block_bytes(nq, k)
         buf = torch.empty(blk, dtype=torch.uint8, device=self.device)
-        # the library drains its own stream before returning, so the block can go straight into
-        # the collective on torch's stream
-        self.table.search_device(q_words, q_nbytes, k, buf.data_ptr(), buf.data_ptr() + rec_bytes, max_hamming=max_hamming)
+        self.table.search_device(q_words, q_nbytes, k, buf.data_ptr(), buf.data_ptr() + rec_bytes, max_hamming=max_hamming,
+                                 consumer_stream=None if synchronous else self._stream())
         return buf
 
     def merge(self, gathered, n_lists, nq, k):
+        """Merge ordered behind torch's current stream (where the gathered blocks were produced): one copy, one synchronisation."""
         rec_bytes, blk = block_bytes(nq, k)
-        self.torch.cuda.synchronize(self.device)   # the all-gather ran on torch's / RCCL's stream
         base = gathered.data_ptr()
-        return self.engine.merge_device(n_lists, nq, k, self.key_words, base, base + rec_bytes, blk, blk)
+        return self.engine.merge_device(n_lists, nq, k, self.key_words, base, base + rec_bytes, blk, blk, after_stream=self._stream())
 
 
 class ShardedTable:
@@ -114,8 +123,16 @@ class ShardedTable:
         return out
 
     def _search(self, q_words, q_nbytes, k, max_hamming):
+        out = self._exchange(q_words, q_nbytes, k, max_hamming, {})
+        if np.any(out[3] == COUNT_OVERFLOW):
+            # some shard's candidate list overflowed and the asynchronous search could only mark it; the merged counts are
+            # the same on every rank, so every rank repeats the step through the synchronous path (exact fallback) together
+            out = self._exchange(q_words, q_nbytes, k, max_hamming, {"synchronous": True})
+        return out
+
+    def _exchange(self, q_words, q_nbytes, k, max_hamming, how):
         nq = q_words.shape[0]
-        block = self.ops.local_search(q_words, q_nbytes, k) if max_hamming is None else self.ops.local_search(q_words, q_nbytes, k, max_hamming)
+        block = self.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else self.ops.local_search(q_words, q_nbytes, k, max_hamming, **how)
         if self.world_size == 1 and not (self.always_gather and self.dist.is_initialized()):
             return self.ops.merge(block, 1, nq, k)
         import torch

@@ -117,3 +117,41 @@ def test_sharded_manager_on_two_processes_equals_the_oracle_backed_unsharded_man
         assert len(got) == len(want)
         for i, (g, w) in enumerate(zip(got, want)):
             assert g == w, f"rank {rank}, answer {i}"
+
+
+def test_asynchronous_step_marks_overflow_and_the_step_is_repeated_exactly(hip_engine):
+    """
+    The multi-GPU step runs without host round-trips (isccsearch_search_device_async -> collective -> merge_device_after).
+    A candidate list that overflows cannot take the exact fallback there: it is marked (COUNT_OVERFLOW), the marker survives
+    the merge, and ShardedTable repeats the step through the synchronous path.  120 000 identical codes overflow every list.
+    """
+    from iscc_search_amd import _lib
+    from iscc_search_amd.sharded import HipShardOps, ShardedTable, block_bytes
+    from oracle import oracle_topk
+
+    import torch
+
+    n, k = 120_000, 10
+    words = np.full((n, 1), 0x2222222222222222, dtype=np.uint64)
+    words[::5] ^= np.uint64(3)
+    keys = np.arange(n, dtype=np.uint64)[::-1].copy() + np.uint64(9)
+    q = np.array([[0x2222222222222222], [0x2222222222222221], [0x0F0F0F0F0F0F0F0F]], dtype=np.uint64)
+    t = hip_engine.open_table(0, 1, 8)
+    try:
+        t.add(keys, words)
+        # the raw asynchronous call: overflowed queries carry the marker, the others are complete
+        rec_bytes, blk = block_bytes(len(q), k)
+        buf = torch.empty(blk, dtype=torch.uint8, device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        t.search_device(q, None, k, buf.data_ptr(), buf.data_ptr() + rec_bytes, consumer_stream=stream)
+        merged = hip_engine.merge_device(1, len(q), k, 1, buf.data_ptr(), buf.data_ptr() + rec_bytes, blk, blk, after_stream=stream)
+        assert (merged[3] == _lib.COUNT_OVERFLOW).any()
+        # the product path repeats the step synchronously and ends up bit-identical to the oracle
+        before = hip_engine.stats()["fallback_queries"]
+        got = ShardedTable(HipShardOps(t, "cuda:0")).search(q, None, k)
+        assert hip_engine.stats()["fallback_queries"] > before
+        exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+        for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+            np.testing.assert_array_equal(g, e, err_msg=name)
+    finally:
+        t.drop()

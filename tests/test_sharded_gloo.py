@@ -27,7 +27,7 @@ class OracleShardOps:
         self.table = table
         self.key_words = table.key_words
 
-    def local_search(self, q_words, q_nbytes, k, max_hamming=None):
+    def local_search(self, q_words, q_nbytes, k, max_hamming=None, synchronous=False):
         rec, cnt = self.table.search_records(q_words, q_nbytes, k, max_hamming)
         nq = q_words.shape[0]
         rec_bytes, blk = block_bytes(nq, k)
