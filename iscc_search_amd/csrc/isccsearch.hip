@@ -225,9 +225,17 @@ int seg_reserve(H* h, Table& t, Segment& s, uint64_t need) {
         if (e != hipSuccess) { cleanup(); (void)hipGetLastError(); return fail(-ENOMEM, "hipMalloc(keys) failed: %s", hipGetErrorString(e)); }
     }
     if (s.n) {
-        for (uint32_t w = 0; w < s.W; ++w) HIPOK(hipMemcpyAsync(ncol[w], s.col[w], s.n * 8, hipMemcpyDeviceToDevice, h->stream));
-        HIPOK(hipMemcpyAsync(nkeys, s.keys, s.n * 8 * t.key_words, hipMemcpyDeviceToDevice, h->stream));
-        HIPOK(hipStreamSynchronize(h->stream));
+        // a failure here must not leak the new columns (the old ones stay in place and valid)
+        hipError_t e = hipSuccess;
+        for (uint32_t w = 0; w < s.W && e == hipSuccess; ++w) e = hipMemcpyAsync(ncol[w], s.col[w], s.n * 8, hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nkeys, s.keys, s.n * 8 * t.key_words, hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(h->stream);
+            cleanup();
+            (void)hipGetLastError();
+            return fail(-EIO, "growing a segment to %llu rows failed while copying: %s", (unsigned long long)cap, hipGetErrorString(e));
+        }
     }
     for (uint32_t w = 0; w < s.W; ++w) { if (s.col[w]) (void)hipFree(s.col[w]); s.col[w] = ncol[w]; }
     if (s.keys) (void)hipFree(s.keys);
@@ -857,7 +865,12 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
         return 0;
     }
     if (!strcmp(name, "profile")) { h->profile = value != 0; return 0; }
-    if (!strcmp(name, "nontemporal")) { h->nontemporal = value != 0; return 0; }
+    if (!strcmp(name, "nontemporal")) {
+        // only the non-temporal variant of the scan kernels is built (plain loads measured no faster):
+        // asking for the other one is refused rather than silently ignored
+        if (value == 0) return fail(-EINVAL, "nontemporal=0 is not available: the scan kernels are built with non-temporal loads only");
+        return 0;
+    }
     if (!strcmp(name, "fold")) { h->fold_tau = value ? 11 : 0; return 0; }   // shorthand kept from the experiments
     if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(-EINVAL, "blocks_per_cu must be 1..64"); h->blocks_per_cu = (uint32_t)value; return 0; }
     if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
@@ -1159,6 +1172,9 @@ int isccsearch_remove(isccsearch_handle* h, uint32_t table, uint64_t n, const ui
     HIPOK(hipSetDevice(h->device));
     if ((rc = ensure_index(h, t))) return rc;
     const int KW = t.key_words;
+    // the host index is updated key by key below and the row moves are replayed on the device afterwards: reserve what that
+    // replay needs BEFORE anything changes, so that an allocation failure cannot leave host and device rows disagreeing
+    if ((rc = h->d_misc.ensure((size_t)n * 2))) return rc;
     std::vector<uint64_t> moves[ISCCSEARCH_MAX_BYTES + 1];
     uint64_t removed = 0;
     for (uint64_t i = 0; i < n; ++i) {
