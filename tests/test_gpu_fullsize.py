@@ -16,9 +16,14 @@ from oracle import oracle_splitmix64_fill, oracle_topk
 
 pytestmark = pytest.mark.gpu
 
+import os
+
 ROWS = 100_000_000
 SEED = 0x1511CC00
 K = 10
+# the whole GPU tier can be re-run under other engine options (ISCC_HIP_OPTS, tests/conftest.py): with the matrix cores
+# switched off the "ran on the matrix cores" assertions do not apply
+MFMA_ON = "mfma=0" not in os.environ.get("ISCC_HIP_OPTS", "")
 
 
 def slab_oracle_topk(rows, nbytes, q, k, metric=0, key_words=1, slab=25_000_000, seed=SEED):
@@ -101,7 +106,7 @@ def test_fullsize_properties_and_oracle_spot_check(hip_engine, big):
         np.testing.assert_array_equal(a, b)
     # 64 queries over 100 M rows run on the matrix cores by default; the XOR + popcount kernel (T_q = 8 and the
     # VALU-bound T_q = 16) returns the same bits
-    assert hip_engine.stats()["mfma_launches"] > 0
+    assert hip_engine.stats()["mfma_launches"] > 0 or not MFMA_ON
     hip_engine.set_option("mfma", 0)
     try:
         for tq in (16, 8):
@@ -111,7 +116,7 @@ def test_fullsize_properties_and_oracle_spot_check(hip_engine, big):
                 np.testing.assert_array_equal(a, b)
     finally:
         hip_engine.set_option("queries_per_pass", 8)
-        hip_engine.set_option("mfma", 1)
+        hip_engine.set_option("mfma", 1 if MFMA_ON else 0)
     # bit-exact against the oracle over all 100 M rows for a few queries (one planted, rest random)
     words = oracle_splitmix64_fill(ROWS, SEED, stride=4).reshape(ROWS, 1)
     row_keys = np.arange(ROWS, dtype=np.uint64)
@@ -287,7 +292,7 @@ def test_config3_100m_x_256bit_nphd_1024_queries(hip_engine):
         before = hip_engine.stats()
         keys, ham, pbits, cnt = t.search(q, qn, K)
         after = hip_engine.stats()
-        assert after["mfma_launches"] > before["mfma_launches"] and after["fallback_queries"] == before["fallback_queries"]
+        assert (after["mfma_launches"] > before["mfma_launches"] or not MFMA_ON) and after["fallback_queries"] == before["fallback_queries"]
         check_lists(keys, ham, pbits, cnt, K, 256)
         for j, (r, f) in planted.items():
             assert int(ham[j, 0]) == f and int(keys[j, 0]) == r, (j, ham[j, :3], keys[j, :3])
@@ -297,7 +302,7 @@ def test_config3_100m_x_256bit_nphd_1024_queries(hip_engine):
         try:
             valu = t.search(q, qn, K)
         finally:
-            hip_engine.set_option("mfma", 1)
+            hip_engine.set_option("mfma", 1 if MFMA_ON else 0)
         for a, b, c in zip((keys, ham, pbits, cnt), again, valu):
             np.testing.assert_array_equal(a, b)
             np.testing.assert_array_equal(a, c)
@@ -328,7 +333,7 @@ def test_config5_10m_simprint_tables_128bit_keys_k400(hip_engine, nbytes):
         try:
             valu = t.search(q, None, k)
         finally:
-            hip_engine.set_option("mfma", 1)
+            hip_engine.set_option("mfma", 1 if MFMA_ON else 0)
         for a, b in zip((keys, ham, pbits, cnt), valu):
             np.testing.assert_array_equal(a, b)
         pick = [0, 1, 2, 3, 100, 257, 510, 511]
