@@ -97,12 +97,14 @@ int isccsearch_create(int device_id, isccsearch_handle** out);
 int isccsearch_destroy(isccsearch_handle* h);
 const char* isccsearch_last_error(void);
 
-/* Options: "queries_per_pass" (8|16), "profile" (0|1: time every collect-scan launch with HIP
- * events, read back through isccsearch_stats_get), "stretch_mb" (rows per collect launch, in MB of codes, when
- * several query groups share a launch: they then read the stretch from the caches instead of HBM; default 128,
- * 0 = one streaming pass per group), "fold_tau" (whole 64-bit codes: query groups whose thresholds are all <= this
- * take the folded 3.5-op fast path; default 11, 0 = never); tuning: "blocks_per_cu", "boot_rows", "level_growth",
- * "repick". */
+/* Options: "mfma" (0|1, default 1: batches of >= "mfma_min_queries" (17) queries over >= "mfma_min_rows" (65 536) rows are
+ * scanned on the matrix cores -- bits as FP4 0/+-1, exact f32 sums, csrc/mfma_scan.hip -- instead of XOR + popcount;
+ * "mfma_level_growth" (4): growth of the threshold levels there); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
+ * (0|1: time every collect-scan launch with HIP events, read back through isccsearch_stats_get), "stretch_mb" (XOR + popcount
+ * kernel: rows per collect launch, in MB of codes, when several query groups share a launch: they then read the stretch from the
+ * caches instead of HBM; default 128, 0 = one streaming pass per group), "fold_tau" (whole 64-bit codes: query groups whose
+ * thresholds are all <= this take the folded 3.5-op fast path; default 11, 0 = never); tuning: "blocks_per_cu", "boot_rows",
+ * "level_growth", "repick".  "nontemporal" accepts only 1 (the only variant built). */
 int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);
 int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset);
 

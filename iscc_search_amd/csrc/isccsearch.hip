@@ -446,7 +446,8 @@ struct Batch {
         if (use_mfma(rows)) {
             const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad);
             const uint32_t chunks = (nq_pad + g * 32 - 1) / (g * 32);
-            const uint64_t steps = (rows + 63) / 64;
+            const uint64_t rps = isk::mfma_rows_per_wave_step((int)j.W);
+            const uint64_t steps = (rows + rps - 1) / rps;
             const uint64_t wpb = isk::mfma_waves_per_block();
             const uint64_t bx = std::max<uint64_t>(1, std::min<uint64_t>((steps + wpb - 1) / wpb, std::max<uint32_t>(1, (uint32_t)h->cus * isk::mfma_blocks_per_cu((int)j.W, g) / chunks)));
             const int e = isk::launch_mfma_scan((int)j.W, mode, (uint32_t)bx, g, h->stream, sp);

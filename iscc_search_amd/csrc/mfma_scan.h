@@ -14,7 +14,8 @@ constexpr int MFMA_MAX_LDS = 64 * 1024;   // dynamic LDS ceiling requested for t
 // query groups (32 queries each, an even number) one block keeps in LDS for W compared words
 uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad);
 size_t mfma_lds_bytes(int W, uint32_t groups);
-uint32_t mfma_waves_per_block();   // a wave takes 64 rows per step
+uint32_t mfma_waves_per_block();
+uint32_t mfma_rows_per_wave_step(int W);   // rows a wave takes per step (64, or 32 when a build runs one tile per wave)
 uint32_t mfma_blocks_per_cu(int W, uint32_t groups);   // resident blocks per CU (LDS and register limits)
 // grid = (blocks_x, chunks of groups * 32 queries); returns 0 or a hipError_t from the attribute call (check
 // hipGetLastError() for the launch itself, as with every other kernel)

@@ -38,12 +38,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int MT = 2;                 // row tiles (32 rows) per wave and step
+// row tiles (32 rows) per wave and step: two share every B fragment, threshold read and compare; experiment switch per W
+#ifndef ISK_MFMA_TILES_W4
+#define ISK_MFMA_TILES_W4 2
+#endif
+template <int W> constexpr int mfma_tiles() { return W == 4 ? ISK_MFMA_TILES_W4 : 2; }
 constexpr int MBLOCK = 256;           // 4 waves; a chunk's LDS image is <= 40 KB, so LDS admits four blocks per CU
 // Registers decide: the rare emit path (both accumulator sets live + 64-bit row numbers) peaks at 130-175 VGPRs, i.e. three
 // waves per SIMD for W <= 3 and two for W = 4.  Forcing four (128 VGPRs) spilled to scratch; the prototype measured
 // 3.22 ms with three resident blocks against 3.15 ms with four (profiles/r02_proto_mfma_scan.txt) -- not worth a spill.
-template <int W> constexpr int mfma_min_waves() { return W <= 3 ? 3 : 2; }
+template <int W> constexpr int mfma_min_waves() { return W <= 3 ? 3 : (mfma_tiles<W>() == 1 ? 4 : 2); }
 constexpr int FP4 = 4;                // cbsz / blgp format code of e2m1
 constexpr int SCALE_ONE = 0x7F7F7F7F; // E8M0 block scales 2^0
 
@@ -56,6 +60,7 @@ __device__ __forceinline__ uint32_t nibbles(uint32_t x, int j) { return (x >> j)
 // LDS image of a chunk: B fragments [groups][W][64] v4i | thr[groups * 32] (float) | popc[groups * 32]
 template <int W, int MODE>
 __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(const ScanParams p, const uint32_t groups) {
+    constexpr int MT = mfma_tiles<W>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v4i* lb = reinterpret_cast<v4i*>(smem);
     float* lthr = reinterpret_cast<float*>(smem + (size_t)groups * W * 64 * 16);
@@ -110,12 +115,17 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 
     // a lane's 16 results per tile all belong to query g * 32 + (lane & 31): fold both tiles (two chains), compare once
     auto reduce = [&](const Acc& acc, float thr, uint32_t g, uint64_t st) {
-        float m0 = min3f(acc.t[0][0], acc.t[0][1], acc.t[0][2]);
-        float m1 = min3f(acc.t[1][0], acc.t[1][1], acc.t[1][2]);
+        float m[MT];
 #pragma unroll
-        for (int i = 3; i < 15; i += 2) { m0 = min3f(m0, acc.t[0][i], acc.t[0][i + 1]); m1 = min3f(m1, acc.t[1][i], acc.t[1][i + 1]); }
-        m0 = min3f(m0, acc.t[0][15], acc.t[1][15]);
-        if (__builtin_expect(fminf(m0, m1) <= thr, 0)) {
+        for (int t = 0; t < MT; ++t) m[t] = min3f(acc.t[t][0], acc.t[t][1], acc.t[t][2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) m[t] = min3f(m[t], acc.t[t][i], acc.t[t][i + 1]);
+        float mall;
+        if constexpr (MT == 2) mall = fminf(min3f(m[0], acc.t[0][15], acc.t[1][15]), m[1]);
+        else mall = fminf(m[0], acc.t[0][15]);
+        if (__builtin_expect(mall <= thr, 0)) {
             // rare: result `reg` of tile t is row (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) of that tile.
             // The step number is laundered so that hipcc does not hoist 32 row numbers per lane out of the group loop
             // (that cost 64 VGPRs in the hot loop for a path taken once in ~10^3 group-steps).
@@ -148,7 +158,10 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     // An empty asm naming BOTH accumulator sets right after the first MFMAs of the next group: the fold of the previous
     // group then depends on it, so hipcc can neither hoist that fold above the MFMAs nor give the two sets the same
     // registers (it did both in the prototype and serialised MFMA -> s_nop 10 -> fold).
-    auto pin2 = [&](Acc& x, Acc& y) { asm volatile("" : "+v"(x.t[0]), "+v"(x.t[1]), "+v"(y.t[0]), "+v"(y.t[1])); };
+    auto pin2 = [&](Acc& x, Acc& y) {
+        if constexpr (MT == 2) asm volatile("" : "+v"(x.t[0]), "+v"(x.t[1]), "+v"(y.t[0]), "+v"(y.t[1]));
+        else asm volatile("" : "+v"(x.t[0]), "+v"(y.t[0]));
+    };
     const v4i* lbl = lb + lane;
     const float* lt = lthr + r;
     auto row_of = [&](uint64_t st, int t) { const uint64_t row = (st * MT + t) * 32 + r; return row <= last_row ? row : last_row; };
@@ -256,10 +269,11 @@ uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad) {
 size_t mfma_lds_bytes(int W, uint32_t groups) { return (size_t)groups * W * 64 * 16 + (size_t)groups * 32 * 8; }
 
 uint32_t mfma_waves_per_block() { return MBLOCK / 64; }
+uint32_t mfma_rows_per_wave_step(int W) { return 32u * (uint32_t)(W == 4 ? mfma_tiles<4>() : 2); }
 
 uint32_t mfma_blocks_per_cu(int W, uint32_t groups) {
     const uint32_t by_lds = (uint32_t)((160u * 1024u) / mfma_lds_bytes(W, groups));
-    const uint32_t by_regs = W <= 3 ? 3u : 2u;
+    const uint32_t by_regs = W <= 3 ? 3u : (mfma_tiles<4>() == 1 ? 4u : 2u);
     return by_lds < by_regs ? (by_lds ? by_lds : 1u) : by_regs;
 }
 
