@@ -10,7 +10,7 @@
 // so the (rows x queries x bits) work is a dense contraction.  The XOR + popcount kernel needs 4.5 VALU instructions per
 // (row, query, 64-bit word), each issuing at one wave64 per ~4 cycles per SIMD, and is VALU-bound from ~11 queries per
 // pass on.  Here the products run on the matrix pipe in its cheapest format: FP4 (e2m1: 0x2 = +1,
-// 0xA = -1, 0x0 = 0) through v_mfma_scale_f32_32x32x64_f8f6f4 with both block scales 2^0 -- ONE instruction (32 cycles)
+// 0xA = -1, 0x0 = 0) through v_mfma_f32_32x32x64_f8f6f4 (the unscaled form: block scales 2^0) -- ONE instruction (32 cycles)
 // per 32 rows x 32 queries x 64 bits, f32 accumulation, exact because every partial sum is an integer of magnitude
 // <= 256.  (The int8 form, v_mfma_i32_32x32x32_i8, needs two instructions of the same length per word and measured 1.44x
 // slower: profiles/r02_proto_mfma_scan.txt.)
@@ -49,7 +49,11 @@ constexpr int MBLOCK = 256;           // 4 waves; a chunk's LDS image is <= 40 K
 // 3.22 ms with three resident blocks against 3.15 ms with four (profiles/r02_proto_mfma_scan.txt) -- not worth a spill.
 template <int W> constexpr int mfma_min_waves() { return W <= 3 ? 3 : (mfma_tiles<W>() == 1 ? 4 : 2); }
 constexpr int FP4 = 4;                // cbsz / blgp format code of e2m1
-constexpr int SCALE_ONE = 0x7F7F7F7F; // E8M0 block scales 2^0
+// Both scale operands constant 0: hipcc then selects the UNSCALED encoding, v_mfma_f32_32x32x64_f8f6f4 (no
+// v_mfma_ld_scale prefix, no scale VGPRs), which multiplies as with block scales 2^0.  Same bits as the scaled form with
+// E8M0 scales 0x7F (both checked against a brute-force kernel: tools/proto_mfma_scan.hip, -DPROTO_SCALE=0) and 6 % faster
+// (3.10 vs 3.30 ms per 100 M x 1 024 pass): one instruction less to issue per MFMA.
+constexpr int SCALE_ONE = 0;
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(NT) void mfma_scan(const P p) {
 // results (exact: |dot| <= 64).  LDS image: B fragments [G][64] v4i | thr[nq] (float) | popc[nq].
 // ------------------------------------------------------------------------------------------------------------------
 typedef int v8i __attribute__((ext_vector_type(8)));
+#ifndef PROTO_SCALE
+#define PROTO_SCALE 0x7F7F7F7F   // E8M0 2^0 in every byte; -DPROTO_SCALE=0 makes hipcc select the UNSCALED instruction form
+#endif
 typedef float v16f __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 // dword j (0..3) of a 32-bit half: nibble t holds bit j + 4 t as 0x2 (e2m1 1.0) or 0x0
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NT) void mfma_scan_fp4(const P p) {
     auto mm = [&](Acc& acc, const v4i& b) {
         const v8i b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc.t[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t], b8, zero, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        for (int t = 0; t < T; ++t) acc.t[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t], b8, zero, 4, 4, 0, PROTO_SCALE, 0, PROTO_SCALE);
     };
     const v4i* lbl = lb + lane;
     const float* lt = lthr + r;
