@@ -90,6 +90,16 @@ def roofline_of(st, args, words, regime):
     """The roofline object of one measured leg from the engine's statistics (HIP events around every collect launch)."""
     if not st["scan_launches"] or st["scan_ms"] <= 0:
         return None
+    streaming = regime.startswith("streaming")
+    mfma = st["scan_mfma_launches"] == st["scan_launches"]          # the collect launches ran on the matrix cores
+    if not streaming:
+        # Levels and collect pass are the SAME kernel (MODE_BOTH / MODE_STRETCH instantiations of one body) walking consecutive
+        # stretches of the rows; together they are ~96 % of a step.  The roofline covers all of their launches.  (The HBM-streaming
+        # leg keeps to the collect launches: its levels are cache-resident by construction.)
+        st = dict(st)
+        for a, b in (("scan_launches", "level_launches"), ("scan_pair_words", "level_pair_words"), ("scan_mfma_launches", "level_mfma_launches"),
+                     ("scan_ms", "level_ms"), ("scan_bytes", "sample_bytes")):
+            st[a] = st[a] + st[b]
     secs = st["scan_ms"] / 1e3
     launches = st["scan_launches"]
     out = {
@@ -97,17 +107,18 @@ def roofline_of(st, args, words, regime):
         "avg_launch_ms": st["scan_ms"] / launches,
         "algorithmic_bytes_per_launch": st["scan_bytes"] / launches,       # rows x 8 x words x passes of T_q queries
         "triples_per_launch": st["scan_pair_words"] / launches,            # (row, query, 64-bit word)
+        "scan_ms_per_step": st["scan_ms"] / max(1, st["searches"]),        # device time of the scan launches of one step
         "regime": regime,
     }
-    mfma = st["scan_mfma_launches"] == launches
     if mfma:
         ops = st["scan_pair_words"] * 128.0                                # 64 multiply-adds per triple
-        # SQ counters of the same kernel (profiles/r02_pmc_sq_mfma_scan.json): the matrix pipe is busy ~45 % of the cycles and
-        # vector issue (the fold: 16 results per lane per 1 024 pairs + the MFMAs' own issue slots) ~80 %; the chip holds ~2.0 GHz
-        out.update({"bound": "mfma", "kernel": "isk::mfma_scan_kernel<W=%d> (v_mfma_scale_f32_32x32x64_f8f6f4, FP4 operands)" % words,
+        # SQ counters of the same kernel (profiles/r02_pmc_sq.json): the matrix pipe is busy ~45 % of the cycles and vector issue
+        # (the fold: 16 results per lane per 1 024 pairs + the MFMAs' own issue slots) ~90 %; the chip holds ~2.05 GHz.
+        # (The first one or two levels of a step cover < 65 536 rows and run on the XOR + popcount kernel: < 1 % of the time.)
+        out.update({"bound": "mfma", "kernel": "isk::mfma_scan_kernel<W=%d> (v_mfma_f32_32x32x64_f8f6f4, FP4 operands), levels + collect" % words,
                     "achieved": ops / secs / 1e12, "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s (FP4, dense)",
                     "co_limiter": "vector issue: the per-result fold shares the SIMD's issue port with the MFMAs"})
-    elif regime.startswith("streaming"):
+    elif streaming:
         out.update({"bound": "hbm", "kernel": "isk::scan_adapt_kernel / scan_kernel (XOR + popcount), one pass of T_q queries per table read",
                     "achieved": st["scan_bytes"] / 1e9 / secs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "measured_copy_ceiling_GBs": 6290.0, "measured_read_ceiling_GBs": 7050.0})

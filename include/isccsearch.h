@@ -90,6 +90,11 @@ typedef struct isccsearch_stats {
     uint64_t mfma_pair_words; /* (row, query, 64-bit word) triples those launches scored: 128 operations each   */
     uint64_t scan_pair_words; /* (row, REAL query, word) triples of the collect launches counted in scan_launches / scan_ms */
     uint64_t scan_mfma_launches; /* how many of scan_launches ran on the matrix cores                          */
+    /* the threshold levels (the first stretch of every segment, same scan kernels in MODE_BOTH), timed like the collect launches */
+    uint64_t level_launches;
+    uint64_t level_pair_words;
+    uint64_t level_mfma_launches;
+    double   level_ms;
 } isccsearch_stats;
 
 /* Engine lifetime.  One handle drives one GPU (one process per GPU). */

@@ -55,6 +55,10 @@ class Stats(ctypes.Structure):
         ("mfma_pair_words", ctypes.c_uint64),
         ("scan_pair_words", ctypes.c_uint64),
         ("scan_mfma_launches", ctypes.c_uint64),
+        ("level_launches", ctypes.c_uint64),
+        ("level_pair_words", ctypes.c_uint64),
+        ("level_mfma_launches", ctypes.c_uint64),
+        ("level_ms", ctypes.c_double),
     ]
 
     def as_dict(self):

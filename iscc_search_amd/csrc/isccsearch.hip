@@ -184,6 +184,7 @@ struct isccsearch_handle {
     hipEvent_t ev_done = nullptr, ev_staged = nullptr, ev_producer = nullptr;
     bool ev_staged_pending = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<char> ev_level;      // per used pair: 1 = a threshold-level launch, 0 = a collect launch
     size_t ev_used = 0;
     isccsearch_stats stats{};
 };
@@ -349,7 +350,7 @@ uint32_t scan_grid_x(H* h, int W, uint64_t rows, uint32_t groups = 1, bool sampl
 }
 
 int drain_events(H* h);
-int event_pair(H* h, hipEvent_t& a, hipEvent_t& b) {
+int event_pair(H* h, hipEvent_t& a, hipEvent_t& b, bool level = false) {
     // a caller that profiles for a long time without reading the statistics must not grow the pool without bound
     if (h->ev_used >= 4096) { int rc = drain_events(h); if (rc) return rc; }
     if (h->ev_used == h->ev_pool.size()) {
@@ -360,6 +361,8 @@ int event_pair(H* h, hipEvent_t& a, hipEvent_t& b) {
     }
     a = h->ev_pool[h->ev_used].first;
     b = h->ev_pool[h->ev_used].second;
+    if (h->ev_level.size() <= h->ev_used) h->ev_level.resize(h->ev_used + 1);
+    h->ev_level[h->ev_used] = level ? 1 : 0;
     ++h->ev_used;
     return 0;
 }
@@ -371,7 +374,7 @@ int drain_events(H* h) {
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.f;
         HIPOK(hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
-        h->stats.scan_ms += ms;
+        if (h->ev_level[i]) h->stats.level_ms += ms; else h->stats.scan_ms += ms;
     }
     h->ev_used = 0;
     return 0;
@@ -606,7 +609,15 @@ struct Batch {
                 }
                 sp.row_begin = done;
                 sp.n_rows = end;
-                if ((rc = scan(j, sp, isk::MODE_BOTH, true))) return rc;
+                {
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    if (h->profile) { if ((rc = event_pair(h, e0, e1, true))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
+                    if ((rc = scan(j, sp, isk::MODE_BOTH, true))) return rc;
+                    if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+                    h->stats.level_launches += 1;
+                    h->stats.level_pair_words += (end - done) * (uint64_t)nq * j.W;
+                    if (use_mfma(end - done)) h->stats.level_mfma_launches += 1;
+                }
                 isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, end), h->d_cnt.p, h->d_cand.p, cap};
                 hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
                 h->stats.sample_bytes += (end - done) * 8 * j.W * groups;

@@ -24,12 +24,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
-DOMINANT = {"mfma": "mfma_scan_kernel<1, 3>", "valu": "scan_adapt_kernel<8, 3>", "streaming": "scan_adapt_kernel<8, 3>", "config3": "mfma_scan_kernel<4, 3>"}
+# kernel name prefixes: levels (<.., 2>) and collect (<.., 3>) are two instantiations of one body; the streaming leg keeps to the collect launches
+DOMINANT = {"mfma": "mfma_scan_kernel<1,", "valu": "scan_adapt_kernel<8,", "streaming": "scan_adapt_kernel<8, 3>", "config3": "mfma_scan_kernel<4,"}
 
 
 def one(pattern):
-    hits = glob.glob(os.path.join(src, pattern), recursive=True)
-    return hits[0] if hits else None
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)      # gpurun MERGES outputs: an older run's files may still be there
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def dispatches(path, kernel):
