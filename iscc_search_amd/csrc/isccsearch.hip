@@ -454,7 +454,7 @@ struct Batch {
             const uint64_t wpb = isk::mfma_waves_per_block();
             const uint64_t bx = std::max<uint64_t>(1, std::min<uint64_t>((steps + wpb - 1) / wpb, std::max<uint32_t>(1, (uint32_t)h->cus * isk::mfma_blocks_per_cu((int)j.W, g) / chunks)));
             const int e = isk::launch_mfma_scan((int)j.W, mode, (uint32_t)bx, g, h->stream, sp);
-            if (e) return fail(-EIO, "mfma scan: hipFuncSetAttribute failed: %s", hipGetErrorString((hipError_t)e));
+            if (e) return fail(-EIO, "mfma scan: chunk of %u query groups does not fit the LDS budget (%s)", g, hipGetErrorString((hipError_t)e));
             h->stats.mfma_launches += 1;
             h->stats.mfma_pair_words += rows * (uint64_t)nq * j.W;
             return 0;

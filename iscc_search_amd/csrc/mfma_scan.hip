@@ -245,18 +245,10 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 
 template <int W>
 static int launch_w(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
-    static bool attr_set[4] = {false, false, false, false};
-    auto set = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_MAX_LDS); };
-    const int mi = mode == MODE_COLLECT ? 0 : (mode == MODE_STRETCH ? 1 : 2);
-    if (!attr_set[mi]) {
-        hipError_t e = mi == 0 ? set(reinterpret_cast<const void*>(&mfma_scan_kernel<W, MODE_COLLECT>))
-                     : mi == 1 ? set(reinterpret_cast<const void*>(&mfma_scan_kernel<W, MODE_STRETCH>))
-                               : set(reinterpret_cast<const void*>(&mfma_scan_kernel<W, MODE_BOTH>));
-        if (e != hipSuccess) return (int)e;
-        attr_set[mi] = true;
-    }
-    if (mi == 0) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_COLLECT>), grid, dim3(MBLOCK), lds, st, p, groups);
-    else if (mi == 1) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_STRETCH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    // a chunk's LDS image is <= 40 KB: inside the default dynamic-LDS limit, no per-device function attribute to set
+    if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
+    if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_COLLECT>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_STRETCH>), grid, dim3(MBLOCK), lds, st, p, groups);
     else hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_BOTH>), grid, dim3(MBLOCK), lds, st, p, groups);
     return 0;
 }

@@ -547,6 +547,9 @@ class HipIndexManager:
         self._indexes = {}  # type: Dict[str, HipIndex]
         self._on_disk = set()
         self._lock = threading.RLock()
+        # sharded mode is SPMD: every rank must issue the same calls in the same order (each holds collectives), so calls that
+        # reach the engine are serialised per manager; a single-GPU manager lets them run concurrently (the engine combines them)
+        self._spmd = threading.RLock() if self.devices > 1 else None
         self._closed = False
         if self.base_path:
             os.makedirs(self.base_path, exist_ok=True)
@@ -640,6 +643,9 @@ class HipIndexManager:
         # type: (str, List[IsccEntry]) -> List[IsccAddResult]
         with self._lock:
             idx = self._index(index_name)
+        if self._spmd is not None:
+            with self._spmd:
+                return idx.add_assets(assets)
         return idx.add_assets(assets)
 
     def get_asset(self, index_name, iscc_id):
@@ -656,6 +662,9 @@ class HipIndexManager:
         with self._lock:
             idx = self._index(index_name)
         try:
+            if self._spmd is not None:
+                with self._spmd:
+                    return idx.search_assets(query, limit)
             return idx.search_assets(query, limit)
         except FileNotFoundError:
             raise FileNotFoundError(f"Asset '{query.iscc_id}' not found in index '{index_name}'")
