@@ -502,11 +502,11 @@ struct Batch {
             if ((rc = h->d_lists.ensure(jobs.size() * (size_t)nq * k))) return rc;
             if ((rc = h->d_listcnt.ensure(jobs.size() * (size_t)nq))) return rc;
         }
-        // stage queries through pinned memory: [nq_pad][4], padded words zero
+        // stage queries through pinned memory: [nq_pad][4], padded words zero.  An asynchronous caller may come back before the
+        // previous batch's query upload has left the staging buffer: wait for it before the buffer is grown or rewritten
+        if (h->ev_staged_pending) { HIPOK(hipEventSynchronize(h->ev_staged)); h->ev_staged_pending = false; }
         if ((rc = h->p_queries.ensure(pq_off + (size_t)nq_pad * 4))) return rc;   // (no-op when the caller pre-sized it)
         uint64_t* const pq = h->p_queries.p + pq_off;
-        // an asynchronous caller may come back before the previous batch's query upload has left the pinned staging buffer
-        if (h->ev_staged_pending) { HIPOK(hipEventSynchronize(h->ev_staged)); h->ev_staged_pending = false; }
         memset(pq, 0, (size_t)nq_pad * 4 * 8);
         for (uint32_t q = 0; q < nq; ++q)
             for (int w = 0; w < t.max_words; ++w) pq[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
@@ -1614,6 +1614,7 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         pq_words += ((size_t)r.nq + 16) * 4;
     }
     int rc;
+    if (h->ev_staged_pending) { HIPOK(hipEventSynchronize(h->ev_staged)); h->ev_staged_pending = false; }   // see Batch::begin
     if ((rc = h->p_queries.ensure(pq_words))) return rc;
     if ((rc = h->p_block.ensure(block_total))) return rc;
     if ((rc = h->d_block.ensure(block_max))) return rc;
