@@ -83,6 +83,27 @@ def test_search_many(forced):
     many.test_search_many_equals_the_oracle_in_every_order(forced)
 
 
+@pytest.mark.parametrize("k,key_words", [(4096, 1), (1000, 2)])
+def test_largest_k_on_the_matrix_cores(forced, k, key_words):
+    """The engine's k ceiling (simprint-sized result lists): candidate handling and select under the matrix-core scan."""
+    rng = np.random.default_rng(k)
+    n, nq = 60_000, 40
+    words = rng.integers(0, 2**64, size=(n, 2), dtype=np.uint64)
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
+    if key_words == 2:
+        keys = np.stack([rng.integers(1, 500, size=n).astype(np.uint64), keys], axis=1)
+    q = words[rng.integers(0, n, size=nq)] ^ np.uint64(0x11)
+    t = forced.open_table(0, key_words, 16)
+    try:
+        t.add(keys, words)
+        got = t.search(q, None, k)
+        exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=16)
+        for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+            np.testing.assert_array_equal(g, e, err_msg=name)
+    finally:
+        t.drop()
+
+
 @pytest.mark.parametrize("nbytes,metric", [(8, 0), (32, 1), (20, 0)])
 def test_large_batch_under_default_thresholds(hip_engine, nbytes, metric):
     """1 000 queries over 400 003 rows: levels and collect pass run on the matrix cores, bit-exact against the oracle."""
