@@ -16,6 +16,11 @@ contract (``iscc_search/indexes/usearch/manager.py:43-46``); what this replaces 
   ``{records | counts}`` blocks, k-way merge on every rank (``sharded.ShardedTable``);
 * ``contains`` / ``get`` / ``size`` / ``remove``'s count are answered by the owner and combined with one small
   all-reduce each -- the key -> rank map is the hash itself, no host table is needed.
+
+SPMD discipline (as for any ``torch.distributed`` program): every rank must make the same calls in the same order --
+``HipIndexManager`` serialises the calls that reach the engine -- and an exception raised on ONE rank only (a device
+allocation failing on one GPU) leaves the others waiting in their collective: run the ranks under a launcher that tears the
+job down when one exits (``torch.distributed.run`` does).
 """
 
 import os
