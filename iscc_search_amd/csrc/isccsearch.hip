@@ -127,6 +127,8 @@ struct PinBuf {   // page-locked host memory: async copies really are asynchrono
     void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
 };
 
+constexpr size_t DIRECT_RESULT_BYTES = 1 << 20;   // result blocks up to this size are written by the kernels straight into pinned host memory
+
 uint64_t mask_for(uint32_t pbytes) {   // mask of the last compared word for a prefix of pbytes bytes
     const uint32_t rem = pbytes & 7;
     return rem ? ~0ULL << (8 * (8 - rem)) : ~0ULL;
@@ -162,12 +164,18 @@ struct isccsearch_handle {
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
+    // k <= 64 on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
+    // every launch of the chain costs ~35 us of ramp, prologue and tail, a step of 100 M rows had seven of them
+    bool self_tighten = true;
+    uint64_t self_boot_rows = 65536;  // its bootstrap sample: all waves start under the sample's threshold at once, so a
+                                      // short sample floods the first steps with candidates (4 096 rows: ~860 per query)
     uint64_t mfma_level_growth = 4;   // threshold levels when the scan runs on the matrix cores (k <= 64): 4 / 6 / 8 measured 295.5 / 295.9 / 290.4 k q/s at 100 M rows and 1.35 / 1.28 / 1.27 M at 12.5 M
     // NPHD distance ranks: rank[p_bytes][h] (u16), row 0 = identity (Hamming tables)
     uint16_t* d_rank = nullptr;
     // scratch
     DevBuf<uint64_t> d_queries;     // [nq_pad][4]
     DevBuf<uint32_t> d_bias, d_cnt, d_ghist, d_overflow, d_listcnt, d_outcnt, d_freq;
+    DevBuf<float> d_thr;            // [nq_pad] live thresholds of the self-tightening pass
     DevBuf<uint64_t> d_cand;
     DevBuf<isk::Record> d_lists, d_final;
     PinBuf<uint64_t> p_queries;     // pinned staging: queries in, flags / results out
@@ -424,6 +432,7 @@ struct Batch {
         c.sp.queries = h->d_queries.p; c.sp.bias = h->d_bias.p; c.sp.cnt = h->d_cnt.p; c.sp.cand = h->d_cand.p;
         c.sp.ghist = h->d_ghist.p; c.sp.cap = cap; c.sp.k = k; c.sp.fold_tau = h->fold_tau; c.sp.nq_pad = nq_pad;
         c.sp.mask_lo = (uint32_t)j.mask_last; c.sp.mask_hi = (uint32_t)(j.mask_last >> 32);
+        c.sp.thr_live = h->d_thr.p;
         c.sl.cnt = h->d_cnt.p; c.sl.cand = h->d_cand.p; c.sl.cap = cap; c.sl.keys = s.keys;
         c.sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
         c.sl.out = multi ? h->d_lists.p + ji * (size_t)nq * k : d_out;
@@ -491,6 +500,7 @@ struct Batch {
         int rc;
         if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;
         if ((rc = h->d_bias.ensure(nq_pad))) return rc;
+        if ((rc = h->d_thr.ensure(nq_pad))) return rc;
         if ((rc = h->d_cnt.ensure((size_t)nq_pad * isk::CNT_STRIDE))) return rc;
         if ((rc = h->d_ghist.ensure((size_t)nq_pad * isk::HB))) return rc;
         if (!d_flags) {
@@ -525,7 +535,7 @@ struct Batch {
             // caches for every further group -- the pass is then bound by the VALU, not by HBM.
             const uint64_t tile_rows = (uint64_t)tile_rows_for((int)j.W);
             bool hist_live = false;
-            auto collect_from = [&](uint64_t from) -> int {
+            auto collect_from = [&](uint64_t from, bool self = false) -> int {
                 uint64_t stretch = s.n;
                 // (the MFMA kernel reads the rows once per CHUNK of up to 1 024 / W queries: one chunk has nothing to share)
                 const bool shared = use_mfma(s.n - from) ? nq_pad > isk::mfma_groups_per_chunk((int)j.W, nq_pad) * 32 : groups > 1;
@@ -544,8 +554,10 @@ struct Batch {
                     // (the last stretch keeps the histogram too -- a handful of atomics -- so that the whole pass is ONE
                     // kernel instantiation, MODE_STRETCH; it just is not followed by a pick)
                     const bool hist_too = h->repick && radius < 0;
-                    const bool repick = hist_too && b < s.n;
-                    if (hist_too) {
+                    const bool repick = hist_too && b < s.n && !self;
+                    if (self) {
+                        if ((rcl = scan(j, sp, isk::MODE_SELF, false))) return rcl;
+                    } else if (hist_too) {
                         if (!hist_live) { HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream)); hist_live = true; }
                         if ((rcl = scan(j, sp, isk::MODE_STRETCH, false))) return rcl;
                     } else {
@@ -577,11 +589,25 @@ struct Batch {
             }
 
             // 1. bootstrap threshold from the first s0 rows
-            const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
+            const bool self = h->self_tighten && k <= 64 && use_mfma(s.n);
+            const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(self ? h->self_boot_rows : h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
             isk::BootParams bp{};
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
             bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.cnt = h->d_cnt.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
+            bp.thr = self ? h->d_thr.p : nullptr;
             hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
+
+            if (self) {
+                // 2'. ONE pass over all rows (in cache-sized stretches when several chunks of queries share them): every wave
+                //     appends what lies within the live threshold of its query and counts it per distance; the lane that proves
+                //     "k rows within t" lowers the threshold for everybody (mfma_scan.hip, MODE_SELF).  No levels, no picks;
+                //     the lists stay unpruned (~k ln(n / s0) entries + ties) and select_kernel takes the exact top-k.
+                HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
+                if ((rc = collect_from(0, true))) return rc;
+                launch_select(c.sl, nq);
+                HIPOK(hipGetLastError());
+                continue;
+            }
 
             // 2. levels: every level streams the NEXT stretch of rows [done, end) exactly once under the threshold of the
             //    rows before it, collecting its candidates and adding them to the running histogram (MODE_BOTH);
@@ -852,7 +878,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         for (auto& t : h->tables)
             if (t) for (auto& s : t->seg) seg_free(s);
         h->tables.clear();
-        h->d_queries.release(); h->d_bias.release(); h->d_cnt.release(); h->d_ghist.release(); h->d_freq.release();
+        h->d_queries.release(); h->d_bias.release(); h->d_thr.release(); h->d_cnt.release(); h->d_ghist.release(); h->d_freq.release();
         h->d_overflow.release(); h->d_listcnt.release(); h->d_outcnt.release(); h->d_cand.release();
         h->d_lists.release(); h->d_final.release(); h->d_misc.release(); h->d_misc2.release();
         h->p_queries.release(); h->p_flags.release();
@@ -892,6 +918,8 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
+    if (!strcmp(name, "self_tighten")) { h->self_tighten = value != 0; return 0; }
+    if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
@@ -1384,15 +1412,20 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         const size_t block_bytes = rec_bytes + ((size_t)m + flag_slots) * sizeof(uint32_t);
         if ((rc = h->d_block.ensure(block_bytes))) return rc;
         if ((rc = h->p_block.ensure(block_bytes))) return rc;
-        isk::Record* const d_rec = reinterpret_cast<isk::Record*>(h->d_block.p);
-        uint32_t* const d_cnt = reinterpret_cast<uint32_t*>(h->d_block.p + rec_bytes);
         const isk::Record* const p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p);
         uint32_t* const p_cnt = reinterpret_cast<uint32_t*>(h->p_block.p + rec_bytes);
         uint32_t segments = 0;
         for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) segments += t.seg[b].n ? 1 : 0;
+        const bool one_copy = segments == 1 && !out_freq;   // flags ride in the block: results leave in ONE copy
+        // ... or in none: select_kernel writes a small block straight into the pinned mirror (page-locked memory is mapped
+        // into the device's address space), so the host only synchronises.  A device->host copy costs ~25 us of queue
+        // hand-over after the kernel, more than the 240 bytes per query take to cross PCIe as plain stores.  Large blocks
+        // (big k x many queries) keep the DMA copy.
+        const bool direct = one_copy && block_bytes <= DIRECT_RESULT_BYTES;
+        isk::Record* const d_rec = reinterpret_cast<isk::Record*>(direct ? h->p_block.p : h->d_block.p);
+        uint32_t* const d_cnt = reinterpret_cast<uint32_t*>((direct ? h->p_block.p : h->d_block.p) + rec_bytes);
         Batch batch(h, t, m, len, k, d_rec, d_cnt);
         batch.radius = radius;
-        const bool one_copy = segments == 1 && !out_freq;   // flags ride in the block: results leave in ONE copy
         if (one_copy) { batch.d_flags = d_cnt + m; batch.h_flags = p_cnt + m; }
         auto copy_results = [&]() -> int {
             if (out_freq) {
@@ -1405,6 +1438,7 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 HIPOK(hipMemcpyAsync(p_cnt, h->d_freq.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
                 return 0;
             }
+            if (direct) return 0;                                  // already written where the host reads it
             const size_t bytes = rec_bytes + (size_t)m * sizeof(uint32_t) + (one_copy ? batch.flag_words() * sizeof(uint32_t) : 0);
             HIPOK(hipMemcpyAsync(h->p_block.p, h->d_block.p, bytes, hipMemcpyDeviceToHost, h->stream));
             return 0;
@@ -1753,23 +1787,22 @@ static int merge_device_impl(isccsearch_handle* h, uint32_t n_lists, uint32_t nq
     std::lock_guard<std::mutex> lk(h->mu);
     HIPOK(hipSetDevice(h->device));
     int rc;
-    if ((rc = h->d_final.ensure((size_t)nq * k))) return rc;
-    if ((rc = h->d_outcnt.ensure(nq))) return rc;
     if (list_stride % 8 || count_stride % 4 || (uintptr_t)d_records % 8 || (uintptr_t)d_counts % 4) return fail(-EINVAL, "misaligned record/count blocks");
     if (ordered) {
         // the gathered blocks are produced on the caller's stream: order the merge behind it without a host round-trip
         HIPOK(hipEventRecord(h->ev_producer, static_cast<hipStream_t>(producer_stream)));
         HIPOK(hipStreamWaitEvent(h->stream, h->ev_producer, 0));
     }
-    isk::MergeParams mp{static_cast<const unsigned char*>(d_records), static_cast<const unsigned char*>(d_counts),
-                        list_stride, count_stride, h->d_final.p, h->d_outcnt.p, n_lists, nq, k};
-    hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
-    HIPOK(hipGetLastError());
-    // ONE pinned block {records | counts}: a single device->host copy and a single synchronisation
+    // The merge writes its {records | counts} straight into ONE pinned host block (page-locked memory is mapped into the
+    // device's address space): 240 bytes per query cross PCIe as the kernel's own stores, and the host needs a single
+    // synchronisation -- no device->host copies to launch (each cost ~25 us of queue hand-over after the kernel).
     const size_t rec_bytes = (size_t)nq * k * sizeof(isk::Record);
     if ((rc = h->p_block.ensure(rec_bytes + (size_t)nq * sizeof(uint32_t)))) return rc;
-    HIPOK(hipMemcpyAsync(h->p_block.p, h->d_final.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPOK(hipMemcpyAsync(h->p_block.p + rec_bytes, h->d_outcnt.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    isk::MergeParams mp{static_cast<const unsigned char*>(d_records), static_cast<const unsigned char*>(d_counts),
+                        list_stride, count_stride, reinterpret_cast<isk::Record*>(h->p_block.p),
+                        reinterpret_cast<uint32_t*>(h->p_block.p + rec_bytes), n_lists, nq, k};
+    hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
+    HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(h->stream));
     unpack_records(reinterpret_cast<const isk::Record*>(h->p_block.p), reinterpret_cast<const uint32_t*>(h->p_block.p + rec_bytes), nq, k, key_words,
                    nullptr, out_keys, out_hamming, out_prefix_bits, out_count);

@@ -504,23 +504,61 @@ struct BootParams {
     uint32_t k;
     uint32_t W;
     uint64_t mask_last;
+    float* thr;               // [nq_pad] out, nullable: tau0 - popc(query) as the MFMA scan compares it (MODE_SELF)
 };
+constexpr uint64_t BOOT_EXACT_ROWS = 4096;   // rows of the full histogram; the rest of a longer sample only counts under its cut
 
-// one block per (padded) query: exact histogram over the first s0 rows -> tau0 = k-th smallest
+// the longer part of the bootstrap sample: rows [s1, s0) that lie at or under `cut` go into the histogram.  W is a
+// template argument so that the eight rows of a trip are eight INDEPENDENT loads (with a run-time word loop hipcc keeps
+// them in program order and the loop waits out one L2 latency per row: 115 us per 65 536 rows instead of ~15)
+template <int W>
+__device__ __forceinline__ void boot_tail(const BootParams& p, const uint64_t (&qw)[4], uint64_t s1, uint32_t cut, uint32_t* hist) {
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t r0 = s1 + tid; r0 < p.s0; r0 += 8 * BLOCK) {
+        uint64_t x[8][W];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t r = r0 + (uint64_t)u * BLOCK;
+            const uint64_t rr = r < p.s0 ? r : s1;          // clamped: the value is discarded below
+#pragma unroll
+            for (int w = 0; w < W; ++w) x[u][w] = p.col[w][rr];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t h = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                uint64_t y = x[u][w] ^ qw[w];
+                if (w == W - 1) y &= p.mask_last;
+                h += (uint32_t)__builtin_popcountll(y);
+            }
+            if (h <= cut && r0 + (uint64_t)u * BLOCK < p.s0) atomicAdd(&hist[h], 1u);
+        }
+    }
+}
+
+// one block per (padded) query: tau0 = k-th smallest hamming over the first s0 rows.  The first BOOT_EXACT_ROWS rows
+// go into a full histogram (LDS atomics on a handful of hot bins: ~6 us); a longer sample then only counts the rows at
+// or under THAT cut -- a few per thousand.
 __global__ __launch_bounds__(BLOCK) void boot_kernel(const BootParams p) {
     __shared__ uint32_t hist[320];
     __shared__ uint32_t res[2];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) p.cnt[(uint64_t)q * CNT_STRIDE] = 0;
     if (q >= p.nq) {
-        if (tid == 0) p.bias[q] = BIAS_NEVER;
+        if (tid == 0) {
+            p.bias[q] = BIAS_NEVER;
+            if (p.thr) p.thr[q] = -1.0e9f;       // below every dot product: never a candidate
+        }
         return;
     }
     for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = 0;
     __syncthreads();
     uint64_t qw[4];
     for (uint32_t w = 0; w < 4; ++w) qw[w] = w < p.W ? p.queries[(uint64_t)q * 4 + w] : 0;
-    for (uint64_t r = tid; r < p.s0; r += BLOCK) {
+    // (a large k keeps the whole sample exact: the cut of the first rows must leave >= k rows under it)
+    const uint64_t s1 = (p.s0 <= BOOT_EXACT_ROWS || (uint64_t)p.k * 4 > BOOT_EXACT_ROWS) ? p.s0 : BOOT_EXACT_ROWS;
+    for (uint64_t r = tid; r < s1; r += BLOCK) {
         uint32_t h = 0;
         for (uint32_t w = 0; w < p.W; ++w) {
             uint64_t x = p.col[w][r] ^ qw[w];
@@ -530,10 +568,27 @@ __global__ __launch_bounds__(BLOCK) void boot_kernel(const BootParams p) {
         atomicAdd(&hist[h], 1u);
     }
     __syncthreads();
-    const uint32_t need = p.k < p.s0 ? p.k : (uint32_t)p.s0;
     uint32_t bin, less;
-    block_find_cut(hist, NBINS, need, res, bin, less);
-    if (tid == 0) p.bias[q] = 0x7FFFFFFFu - bin;
+    block_find_cut(hist, NBINS, p.k < s1 ? p.k : (uint32_t)s1, res, bin, less);
+    if (p.s0 > s1) {
+        // (uniform branch: s0 is a launch parameter)  bins <= `bin` become exact over [0, s0); the k-th smallest lies there
+        switch (p.W) {
+            case 1: boot_tail<1>(p, qw, s1, bin, hist); break;
+            case 2: boot_tail<2>(p, qw, s1, bin, hist); break;
+            case 3: boot_tail<3>(p, qw, s1, bin, hist); break;
+            default: boot_tail<4>(p, qw, s1, bin, hist); break;
+        }
+        __syncthreads();
+        block_find_cut(hist, NBINS, p.k < p.s0 ? p.k : (uint32_t)p.s0, res, bin, less);
+    }
+    if (tid == 0) {
+        p.bias[q] = 0x7FFFFFFFu - bin;
+        if (p.thr) {
+            uint32_t pc = 0;
+            for (uint32_t w = 0; w < p.W; ++w) pc += (uint32_t)__builtin_popcountll(w == p.W - 1 ? qw[w] & p.mask_last : qw[w]);
+            p.thr[q] = (float)((int)bin - (int)pc);
+        }
+    }
 }
 
 struct PickParams {

@@ -37,6 +37,8 @@ namespace isk {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(3))) v4i* lds_frag_ptr;
+typedef const __attribute__((address_space(3))) float* lds_thr_ptr;
 
 // row tiles (32 rows) per wave and step: two share every B fragment, threshold read and compare; experiment switch per W
 #ifndef ISK_MFMA_TILES_W4
@@ -56,10 +58,49 @@ constexpr int FP4 = 4;                // cbsz / blgp format code of e2m1
 constexpr int SCALE_ONE = 0;
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+// a live threshold as other CUs last wrote it: device-scope load, past this CU's vector cache
+__device__ __forceinline__ float live_threshold(const float* addr) {
+    return __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
 // Dword j (0..3) of a 32-bit half: nibble t holds bit j + 4 t.  Rows (A) and queries (B) use the same map, so the k order
 // inside the instruction does not matter; lanes 0..31 carry the low half of a word and lanes 32..63 the high half on both sides.
 __device__ __forceinline__ uint32_t nibbles(uint32_t x, int j) { return (x >> j) & 0x11111111u; }
+
+// MODE_SELF: a candidate whose two atomics (list slot, distance counter) are IN FLIGHT.  Waiting for them on the spot costs
+// the wave ~1 us per candidate (~180 candidates per query over 100 M rows: 0.1 ms of a 3 ms pass); instead the results are
+// consumed at the lane's next candidate or at the end of the step, whichever comes first, when they have long arrived.
+struct Pending {
+    uint32_t slot, before;    // results of the atomics (valid once `meta` says so)
+    uint32_t lo, hi;          // the candidate word (hamming << 48) | row
+    uint32_t meta = 0;        // bit 31: pending; bit 30: `before` counts (hamming < tau_seen); bits 16..24: tau_seen; bits 0..9: query in chunk
+
+    __device__ __forceinline__ void issue(const ScanParams& p, uint32_t q0, uint32_t ql, int h, uint64_t row, int tau_seen) {
+        const uint32_t qi = q0 + ql;
+        const bool counted = h < tau_seen;
+        slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
+        if (counted) before = atomicAdd(&p.ghist[(uint64_t)qi * HB + (uint32_t)h], 1u);
+        lo = (uint32_t)row;
+        hi = ((uint32_t)h << 16) | (uint32_t)(row >> 32);
+        meta = 0x80000000u | (counted ? 0x40000000u : 0u) | ((uint32_t)tau_seen << 16) | ql;
+    }
+    __device__ __forceinline__ void complete(const ScanParams& p, uint32_t q0, const int* lpop) {
+        if (!(meta & 0x80000000u)) return;
+        const uint32_t ql = meta & 0x3FFu, qi = q0 + ql;
+        if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)hi << 32) | lo;
+        if (meta & 0x40000000u) {
+            const int tau_seen = (int)((meta >> 16) & 0x1FFu);
+            uint32_t* const counts = p.ghist + (uint64_t)qi * HB;
+            uint32_t b = before;
+            for (int t = (int)(hi >> 16);;) {       // as emit_self: count under every t < tau_seen until one proves k rows
+                if (b + 1 >= p.k) { lower_threshold(p.thr_live + qi, (float)(t - lpop[ql])); break; }
+                if (++t >= tau_seen) break;
+                b = atomicAdd(&counts[(uint32_t)t], 1u);
+            }
+        }
+        meta = 0;
+    }
+};
 
 // LDS image of a chunk: B fragments [groups][W][64] v4i | thr[groups * 32] (float) | popc[groups * 32]
 template <int W, int MODE>
@@ -101,7 +142,8 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
             tau = (int)(0x7FFFFFFFu - p.bias[q]);       // BIAS_NEVER -> -1: no row can be a candidate
         }
         lpop[ql] = pc;
-        lthr[ql] = (float)(tau - pc);                   // hamming <= tau  <=>  dot <= tau - popc(q)
+        if constexpr (MODE == MODE_SELF) lthr[ql] = q < p.nq_pad ? live_threshold(p.thr_live + q) : -1.0e9f;
+        else lthr[ql] = (float)(tau - pc);              // hamming <= tau  <=>  dot <= tau - popc(q)
     }
     __syncthreads();
 
@@ -117,6 +159,8 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 #pragma unroll
     for (int w = 0; w < W; ++w) col32[w] = reinterpret_cast<const uint32_t*>(p.col[w]);
 
+    constexpr bool ASYNC = W <= 2;       // five more live registers: W = 3 would spill, W = 4 is at two waves per SIMD already
+    Pending pend;
     // a lane's 16 results per tile all belong to query g * 32 + (lane & 31): fold both tiles (two chains), compare once
     auto reduce = [&](const Acc& acc, float thr, uint32_t g, uint64_t st) {
         float m[MT];
@@ -138,15 +182,36 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
             const uint64_t base = (((uint64_t)st_hi << 32) | st_lo) * (32 * MT) + 4 * h;
             const uint32_t ql = g * 32 + r;
             const int pc = lpop[ql];
+            int tau_seen = (int)thr + pc;               // MODE_SELF: the threshold this compare ran under (>= the live one)
+            // MODE_SELF: the FIRST hit of the entry (nearly always the only one) is appended asynchronously -- see Pending
+            uint32_t hits = 0, first_off = 0;
+            float first_dot = 0.f;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     if (acc.t[t][reg] <= thr) {
-                        const uint64_t row = base + (uint32_t)(t * 32 + (reg & 3) + 8 * (reg >> 2));
-                        if (row <= last_row) emit<MODE>(p, q0 + ql, (uint32_t)((int)acc.t[t][reg] + pc), row);
+                        const uint32_t off = (uint32_t)(t * 32 + (reg & 3) + 8 * (reg >> 2));
+                        const uint64_t row = base + off;
+                        if (row <= last_row) {
+                            if constexpr (MODE == MODE_SELF && !ASYNC) {
+                                tau_seen = emit_self(p, q0 + ql, (int)acc.t[t][reg] + pc, row, tau_seen, pc);
+                            } else if constexpr (MODE == MODE_SELF) {
+                                if (hits == 0) { first_dot = acc.t[t][reg]; first_off = off; }
+                                else tau_seen = emit_self(p, q0 + ql, (int)acc.t[t][reg] + pc, row, tau_seen, pc);
+                                hits += 1;
+                            } else {
+                                emit<MODE>(p, q0 + ql, (uint32_t)((int)acc.t[t][reg] + pc), row);
+                            }
+                        }
                     }
                 }
+            if constexpr (MODE == MODE_SELF && ASYNC) {
+                if (hits) {
+                    pend.complete(p, q0, lpop);
+                    pend.issue(p, q0, ql, (int)first_dot + pc, base + first_off, tau_seen);
+                }
+            }
         }
     };
 
@@ -175,8 +240,23 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int w = 0; w < W; ++w) x[t][w] = col32[w][row_of(step, t) * 2 + h];
-    for (; step < nsteps; step += stride) {
+    // MODE_SELF: wave w keeps the block's copy of thresholds [256 w, 256 w + 256) fresh -- requested here, written to LDS
+    // after the group loop, picked up by all four waves from their next step on (a stale threshold is only a looser one)
+    const uint32_t fresh_at = wave * 256 + lane * 4;
+    const bool refresh = MODE == MODE_SELF && fresh_at < groups * 32 && q0 + fresh_at < p.nq_pad;   // nq_pad is a multiple of 8
+    // ... every step when the chunk is full (32 groups), every 32 / groups steps otherwise: about once per 32 group-steps
+    const uint32_t refresh_mask = groups >= 32 ? 0u : groups >= 16 ? 1u : groups >= 8 ? 3u : groups >= 4 ? 7u : 15u;
+    uint32_t trip = 0;
+    for (; step < nsteps; step += stride, ++trip) {
         const uint64_t ns = step + stride < nsteps ? step + stride : step;
+        float fresh[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool refresh_now = refresh && (trip & refresh_mask) == 0;      // (MODE_SELF only: `refresh` is false otherwise)
+        if constexpr (MODE == MODE_SELF) {
+            if (refresh_now) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fresh[i] = live_threshold(p.thr_live + q0 + fresh_at + i);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -194,44 +274,49 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
         v4i bx = lbl[0], by = lbl[0];
         Acc accX, accY;
         float thrX = 0.f, thrY = lt[0];
-        // stage(g, w): consume buffer ((g * W + w) & 1), prefetch the next word into the other one
-        auto stage = [&](Acc& acc, uint32_t g, int w, bool y_buf, bool more) {
-            const uint32_t nxt = (g * W + w + 1) * 64;
+        // stage(w): consume one buffer, prefetch fragment `nxt` (counted from the pair's base pointer, so that the offsets
+        // are immediates of the ds_read and one pointer increment serves two groups) into the other one
+        auto stage = [&](Acc& acc, lds_frag_ptr base, int nxt, int w, bool y_buf, bool more) {
             if (y_buf) {
                 mm(acc, w, by);
-                if (more) bx = lbl[nxt];
+                if (more) bx = base[nxt * 64];
             } else {
                 mm(acc, w, bx);
-                if (more) by = lbl[nxt];
+                if (more) by = base[nxt * 64];
             }
         };
         // group 0
 #pragma unroll
-        for (int w = 0; w < W; ++w) stage(accY, 0, w, (w & 1) == 0, true);
+        for (int w = 0; w < W; ++w) stage(accY, (lds_frag_ptr)lbl, w + 1, w, (w & 1) == 0, true);
+        // LDS addresses of the pair (g, g + 1): 32-bit pointers advanced by hand and laundered, or hipcc rebuilds both
+        // from g with a shift-add per group (two more vector instructions per pair in a loop that is issue-bound)
+        lds_frag_ptr lg = (lds_frag_ptr)lbl + W * 64;
+        lds_thr_ptr ltg = (lds_thr_ptr)lt + 32;
 #pragma unroll 1
-        for (uint32_t g = 1; g + 1 < groups; g += 2) {
+        for (uint32_t g = 1; g + 1 < groups; g += 2, lg += 2 * W * 64, ltg += 64) {
+            asm volatile("" : "+v"(lg), "+v"(ltg));
             // odd group g -> accX; its first word sits in buffer parity (W & 1): Y when W is even
-            thrX = lt[g * 32];
+            thrX = ltg[0];
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                stage(accX, g, w, ((W + w) & 1) == 0, true);
+                stage(accX, lg, w + 1, w, ((W + w) & 1) == 0, true);
                 if (w == 0) { pin2(accX, accY); reduce(accY, thrY, g - 1, step); }
             }
             // even group g + 1 -> accY; (2 * W + w) & 1 == w & 1
-            thrY = lt[(g + 1) * 32];
+            thrY = ltg[32];
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                stage(accY, g + 1, w, (w & 1) == 0, true);
+                stage(accY, lg, W + w + 1, w, (w & 1) == 0, true);
                 if (w == 0) { pin2(accY, accX); reduce(accX, thrX, g, step); }
             }
         }
         // last (odd) group: nothing further to prefetch after its last word
         {
             const uint32_t g = groups - 1;
-            thrX = lt[g * 32];
+            thrX = ltg[0];
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                stage(accX, g, w, ((W + w) & 1) == 0, w + 1 < W);
+                stage(accX, lg, w + 1, w, ((W + w) & 1) == 0, w + 1 < W);
                 if (w == 0) { pin2(accX, accY); reduce(accY, thrY, g - 1, step); }
             }
             reduce(accX, thrX, g, step);
@@ -240,7 +325,14 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int w = 0; w < W; ++w) x[t][w] = xn[t][w];
+        if constexpr (MODE == MODE_SELF) {
+            if (refresh_now) *reinterpret_cast<float4*>(lthr + fresh_at) = make_float4(fresh[0], fresh[1], fresh[2], fresh[3]);
+            if constexpr (ASYNC) {
+                if ((trip & refresh_mask) == refresh_mask) pend.complete(p, q0, lpop);
+            }
+        }
     }
+    if constexpr (MODE == MODE_SELF && ASYNC) pend.complete(p, q0, lpop);
 }
 
 template <int W>
@@ -249,6 +341,7 @@ static int launch_w(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanP
     if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
     if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_COLLECT>), grid, dim3(MBLOCK), lds, st, p, groups);
     else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_STRETCH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_SELF) hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_SELF>), grid, dim3(MBLOCK), lds, st, p, groups);
     else hipLaunchKernelGGL((mfma_scan_kernel<W, MODE_BOTH>), grid, dim3(MBLOCK), lds, st, p, groups);
     return 0;
 }

@@ -20,6 +20,9 @@ constexpr int MODE_HIST = 1;      // count candidates per hamming distance
 constexpr int MODE_BOTH = 2;      // both: the threshold levels
 constexpr int MODE_STRETCH = 3;   // as MODE_BOTH, for the stretches of the collect pass: a separate instantiation so that
                                   // profilers tell the pass from the levels by kernel name
+constexpr int MODE_SELF = 4;      // single pass with SELF-TIGHTENING thresholds (mfma_scan.hip): candidates are appended and counted
+                                  // in a cumulative histogram; the lane that makes "k rows within t" true lowers the live
+                                  // threshold of its query, and every wave re-reads the live thresholds once per step
 
 struct ScanParams {
     const uint64_t* col[4];   // segment columns (word-major)
@@ -35,6 +38,7 @@ struct ScanParams {
     uint32_t k;                 // results wanted per query
     uint32_t fold_tau;          // scan_adapt_kernel: groups whose thresholds are all <= this take the folded fast path (0: never)
     uint32_t nq_pad;            // queries (bias entries) behind `queries` / `bias`: the MFMA kernel pads its last chunk itself
+    float* thr_live;            // [nq_pad] MODE_SELF: live threshold of every query as the MFMA kernel compares it: tau - popc(query)
 };
 
 // returns the candidate's slot in the query's list (0 in MODE_HIST)
@@ -47,6 +51,40 @@ __device__ __forceinline__ uint32_t emit(const ScanParams& p, uint32_t qi, uint3
     }
     if constexpr (MODE == MODE_HIST || MODE == MODE_BOTH || MODE == MODE_STRETCH) atomicAdd(&p.ghist[(uint64_t)qi * HB + h], 1u);
     return slot;
+}
+
+// MODE_SELF.  ghist[q][t] counts the appended rows with hamming <= t, for every t BELOW the threshold the appending wave
+// last saw (`tau_seen` >= the live threshold, so every count below the live threshold is complete).  The lane whose row
+// makes count[t] reach k has proved "k appended rows lie within t": it lowers the live threshold to t (a looser leftover
+// from a lost race is harmless: thresholds only decide what is APPENDED, select_kernel picks the exact top-k afterwards).
+__device__ __forceinline__ void lower_threshold(float* addr, float v) {
+    int* a = reinterpret_cast<int*>(addr);
+    int old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__int_as_float(old) > v) {
+        const int prev = atomicCAS(a, old, __float_as_int(v));
+        if (prev == old) break;
+        old = prev;
+    }
+}
+
+// returns the (possibly lowered) threshold this lane goes on with
+__device__ __forceinline__ int emit_self(const ScanParams& p, uint32_t qi, int h, uint64_t row, int tau_seen, int popc_q) {
+    // both atomics are in flight together: one round trip to the L2 per candidate (the common case has h == tau_seen or
+    // tau_seen - 1, i.e. none or one counter to bump)
+    uint32_t* const counts = p.ghist + (uint64_t)qi * HB;
+    const bool counted = h < tau_seen;
+    const uint32_t slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
+    uint32_t before = counted ? atomicAdd(&counts[(uint32_t)h], 1u) : 0u;
+    if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)(uint32_t)h << 48) | row;
+    if (!counted) return tau_seen;
+    for (int t = h;;) {
+        if (before + 1 >= p.k) {
+            lower_threshold(p.thr_live + qi, (float)(t - popc_q));
+            return t;
+        }
+        if (++t >= tau_seen) return tau_seen;
+        before = atomicAdd(&counts[(uint32_t)t], 1u);
+    }
 }
 
 }  // namespace isk

@@ -72,6 +72,12 @@ class HipShardOps:
                                  consumer_stream=None if synchronous else self._stream())
         return buf
 
+    def search_single(self, q_words, q_nbytes, k, max_hamming=None):
+        """The whole answer when this shard is the only one: the host entry point (no result block, no merge launch)."""
+        if max_hamming is None:
+            return self.table.search(q_words, q_nbytes, k)
+        return self.table.search_within(q_words, q_nbytes, k, max_hamming)
+
     def merge(self, gathered, n_lists, nq, k):
         """Merge ordered behind torch's current stream (where the gathered blocks were produced): one copy, one synchronisation."""
         rec_bytes, blk = block_bytes(nq, k)
@@ -132,8 +138,12 @@ class ShardedTable:
 
     def _exchange(self, q_words, q_nbytes, k, max_hamming, how):
         nq = q_words.shape[0]
+        alone = self.world_size == 1 and not (self.always_gather and self.dist.is_initialized())
+        single = getattr(self.ops, "search_single", None)
+        if alone and single is not None:
+            return single(q_words, q_nbytes, k, max_hamming)
         block = self.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else self.ops.local_search(q_words, q_nbytes, k, max_hamming, **how)
-        if self.world_size == 1 and not (self.always_gather and self.dist.is_initialized()):
+        if alone:
             return self.ops.merge(block, 1, nq, k)
         import torch
 
