@@ -167,6 +167,9 @@ struct isccsearch_handle {
     // k <= 64 on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
     // every launch of the chain costs ~35 us of ramp, prologue and tail, a step of 100 M rows had seven of them
     bool self_tighten = true;
+    uint32_t self_refresh_steps = 1;  // steps of a full chunk between two looks at the live thresholds (power of two)
+    uint32_t self_max_k = 512;        // the unpruned lists hold ~17 k entries + the first steps' flood: see the cap in Batch::begin
+                                      // (100 M rows, k = 100 / 256 / 512: 3.80 / 4.52 / 6.04 ms against 4.60 / 5.35 / 7.37 with levels)
     uint64_t self_boot_rows = 65536;  // its bootstrap sample: all waves start under the sample's threshold at once, so a
                                       // short sample floods the first steps with candidates (4 096 rows: ~860 per query)
     uint64_t mfma_level_growth = 4;   // threshold levels when the scan runs on the matrix cores (k <= 64): 4 / 6 / 8 measured 295.5 / 295.9 / 290.4 k q/s at 100 M rows and 1.35 / 1.28 / 1.27 M at 12.5 M
@@ -433,6 +436,7 @@ struct Batch {
         c.sp.ghist = h->d_ghist.p; c.sp.cap = cap; c.sp.k = k; c.sp.fold_tau = h->fold_tau; c.sp.nq_pad = nq_pad;
         c.sp.mask_lo = (uint32_t)j.mask_last; c.sp.mask_hi = (uint32_t)(j.mask_last >> 32);
         c.sp.thr_live = h->d_thr.p;
+        c.sp.refresh_steps = h->self_refresh_steps;
         c.sl.cnt = h->d_cnt.p; c.sl.cand = h->d_cand.p; c.sl.cap = cap; c.sl.keys = s.keys;
         c.sl.rank = h->d_rank + (t.metric == ISCCSEARCH_METRIC_NPHD ? j.pbytes * 257 : 0);
         c.sl.out = multi ? h->d_lists.p + ji * (size_t)nq * k : d_out;
@@ -494,6 +498,8 @@ struct Batch {
             return 0;
         }
         cap = std::max<uint32_t>(16384, 16 * k);
+        // the self-tightening pass never prunes: ~17 k entries per query over 100 M rows (+ the flood of the first steps)
+        if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0) cap = std::max<uint32_t>(cap, 48 * k);
         multi = jobs.size() > 1;
         P = next_pow2(std::max<uint32_t>(k, 1024));   // select's LDS sort buffer: room for small tie classes (12-20 KB)
         sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
@@ -589,20 +595,28 @@ struct Batch {
             }
 
             // 1. bootstrap threshold from the first s0 rows
-            const bool self = h->self_tighten && k <= 64 && use_mfma(s.n);
+            //    Large batches with k <= self_max_k take ONE pass on the matrix cores with self-tightening thresholds (MODE_SELF).
+            //    (The XOR + popcount kernels keep the levels: their resident blocks cover ~4 M rows -- 16 M by the time a second
+            //    tile could see a new threshold -- before any update reaches them, and fresh thresholds must be read past the
+            //    per-XCD L2s (sc1 / glc), where 8 192 waves hammering one line serialise: measured 0.24-0.53 ms for 1-8
+            //    queries over 100 M rows against 0.10 ms for the collect pass of the level design.)
+            const bool self = h->self_tighten && k <= h->self_max_k && use_mfma(s.n);
             const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(self ? h->self_boot_rows : h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
             isk::BootParams bp{};
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
             bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.cnt = h->d_cnt.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
             bp.thr = self ? h->d_thr.p : nullptr;
-            hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(isk::BLOCK), 0, h->stream, bp);
+            bp.counts = h->d_ghist.p;          // zeroed by the kernel: the running histogram of the levels / the counters of MODE_SELF
+            hist_live = true;
+            // one block per query: a handful of queries get wide blocks, or a 65 536-row sample is one block's latency-bound walk
+            hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(nq_pad <= 64 ? 1024 : isk::BLOCK), 0, h->stream, bp);
 
             if (self) {
-                // 2'. ONE pass over all rows (in cache-sized stretches when several chunks of queries share them): every wave
-                //     appends what lies within the live threshold of its query and counts it per distance; the lane that proves
-                //     "k rows within t" lowers the threshold for everybody (mfma_scan.hip, MODE_SELF).  No levels, no picks;
-                //     the lists stay unpruned (~k ln(n / s0) entries + ties) and select_kernel takes the exact top-k.
-                HIPOK(hipMemsetAsync(h->d_ghist.p, 0, (size_t)nq_pad * isk::HB * sizeof(uint32_t), h->stream));
+                // 2'. ONE pass over all rows (in cache-sized stretches when several chunks of queries share them):
+                //     every wave appends what lies within the live threshold of its query and counts it per distance; the lane
+                //     that proves "k rows within t" lowers the threshold for everybody (mfma_scan.hip, MODE_SELF).
+                //     No levels, no picks; the lists stay unpruned (~k ln(n / s0) entries + ties + the first steps' flood) and
+                //     select_kernel takes the exact top-k.  (boot_kernel has zeroed the counters.)
                 if ((rc = collect_from(0, true))) return rc;
                 launch_select(c.sl, nq);
                 HIPOK(hipGetLastError());
@@ -919,6 +933,11 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_tighten")) { h->self_tighten = value != 0; return 0; }
+    if (!strcmp(name, "self_refresh_steps")) {
+        if (value < 1 || value > 64 || (value & (value - 1))) return fail(-EINVAL, "self_refresh_steps must be a power of two in 1..64");
+        h->self_refresh_steps = (uint32_t)value; return 0;
+    }
+    if (!strcmp(name, "self_max_k")) { if (value < 1 || value > 512) return fail(-EINVAL, "self_max_k must be 1..512"); h->self_max_k = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }

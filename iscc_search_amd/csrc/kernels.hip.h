@@ -505,6 +505,7 @@ struct BootParams {
     uint32_t W;
     uint64_t mask_last;
     float* thr;               // [nq_pad] out, nullable: tau0 - popc(query) as the MFMA scan compares it (MODE_SELF)
+    uint32_t* counts;         // [nq_pad][HB], nullable: zeroed here -- the distance counters of the self-tightening pass
 };
 constexpr uint64_t BOOT_EXACT_ROWS = 4096;   // rows of the full histogram; the rest of a longer sample only counts under its cut
 
@@ -513,12 +514,12 @@ constexpr uint64_t BOOT_EXACT_ROWS = 4096;   // rows of the full histogram; the 
 // them in program order and the loop waits out one L2 latency per row: 115 us per 65 536 rows instead of ~15)
 template <int W>
 __device__ __forceinline__ void boot_tail(const BootParams& p, const uint64_t (&qw)[4], uint64_t s1, uint32_t cut, uint32_t* hist) {
-    const uint32_t tid = threadIdx.x;
-    for (uint64_t r0 = s1 + tid; r0 < p.s0; r0 += 8 * BLOCK) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    for (uint64_t r0 = s1 + tid; r0 < p.s0; r0 += 8 * nthr) {
         uint64_t x[8][W];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const uint64_t r = r0 + (uint64_t)u * BLOCK;
+            const uint64_t r = r0 + (uint64_t)u * nthr;
             const uint64_t rr = r < p.s0 ? r : s1;          // clamped: the value is discarded below
 #pragma unroll
             for (int w = 0; w < W; ++w) x[u][w] = p.col[w][rr];
@@ -532,19 +533,22 @@ __device__ __forceinline__ void boot_tail(const BootParams& p, const uint64_t (&
                 if (w == W - 1) y &= p.mask_last;
                 h += (uint32_t)__builtin_popcountll(y);
             }
-            if (h <= cut && r0 + (uint64_t)u * BLOCK < p.s0) atomicAdd(&hist[h], 1u);
+            if (h <= cut && r0 + (uint64_t)u * nthr < p.s0) atomicAdd(&hist[h], 1u);
         }
     }
 }
 
 // one block per (padded) query: tau0 = k-th smallest hamming over the first s0 rows.  The first BOOT_EXACT_ROWS rows
 // go into a full histogram (LDS atomics on a handful of hot bins: ~6 us); a longer sample then only counts the rows at
-// or under THAT cut -- a few per thousand.
-__global__ __launch_bounds__(BLOCK) void boot_kernel(const BootParams p) {
+// or under THAT cut -- a few per thousand.  Any block size from 64 to 1 024 threads: with a handful of queries the host
+// launches wide blocks, or the sample of a query would be one block's latency-bound walk.
+__global__ __launch_bounds__(1024) void boot_kernel(const BootParams p) {
     __shared__ uint32_t hist[320];
     __shared__ uint32_t res[2];
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     if (tid == 0) p.cnt[(uint64_t)q * CNT_STRIDE] = 0;
+    if (p.counts)
+        for (uint32_t i = tid; i < HB; i += nthr) p.counts[(uint64_t)q * HB + i] = 0;      // (saves the host a memset launch)
     if (q >= p.nq) {
         if (tid == 0) {
             p.bias[q] = BIAS_NEVER;
@@ -552,13 +556,13 @@ __global__ __launch_bounds__(BLOCK) void boot_kernel(const BootParams p) {
         }
         return;
     }
-    for (uint32_t i = tid; i < 320; i += BLOCK) hist[i] = 0;
+    for (uint32_t i = tid; i < 320; i += nthr) hist[i] = 0;
     __syncthreads();
     uint64_t qw[4];
     for (uint32_t w = 0; w < 4; ++w) qw[w] = w < p.W ? p.queries[(uint64_t)q * 4 + w] : 0;
     // (a large k keeps the whole sample exact: the cut of the first rows must leave >= k rows under it)
     const uint64_t s1 = (p.s0 <= BOOT_EXACT_ROWS || (uint64_t)p.k * 4 > BOOT_EXACT_ROWS) ? p.s0 : BOOT_EXACT_ROWS;
-    for (uint64_t r = tid; r < s1; r += BLOCK) {
+    for (uint64_t r = tid; r < s1; r += nthr) {
         uint32_t h = 0;
         for (uint32_t w = 0; w < p.W; ++w) {
             uint64_t x = p.col[w][r] ^ qw[w];

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     // after the group loop, picked up by all four waves from their next step on (a stale threshold is only a looser one)
     const uint32_t fresh_at = wave * 256 + lane * 4;
     const bool refresh = MODE == MODE_SELF && fresh_at < groups * 32 && q0 + fresh_at < p.nq_pad;   // nq_pad is a multiple of 8
-    // ... every step when the chunk is full (32 groups), every 32 / groups steps otherwise: about once per 32 group-steps
-    const uint32_t refresh_mask = groups >= 32 ? 0u : groups >= 16 ? 1u : groups >= 8 ? 3u : groups >= 4 ? 7u : 15u;
+    // ... every `refresh_steps` steps when the chunk is full (32 groups), proportionally less often for smaller chunks
+    const uint32_t refresh_mask = (groups >= 32 ? 1u : groups >= 16 ? 2u : groups >= 8 ? 4u : groups >= 4 ? 8u : 16u) * p.refresh_steps - 1u;
     uint32_t trip = 0;
     for (; step < nsteps; step += stride, ++trip) {
         const uint64_t ns = step + stride < nsteps ? step + stride : step;

@@ -39,6 +39,7 @@ struct ScanParams {
     uint32_t fold_tau;          // scan_adapt_kernel: groups whose thresholds are all <= this take the folded fast path (0: never)
     uint32_t nq_pad;            // queries (bias entries) behind `queries` / `bias`: the MFMA kernel pads its last chunk itself
     float* thr_live;            // [nq_pad] MODE_SELF: live threshold of every query as the MFMA kernel compares it: tau - popc(query)
+    uint32_t refresh_steps;     // MODE_SELF: a wave re-reads its share of the live thresholds every this many steps of a full chunk (power of two)
 };
 
 // returns the candidate's slot in the query's list (0 in MODE_HIST)

@@ -84,3 +84,63 @@ def test_rejects_missing_wait_state_pad_scratch_and_spills(tmp_path):
     assert rc == 1 and "scratch" in out
     rc, out = run(tmp_path, spill=2)
     assert rc == 1 and "VGPR spills" in out
+
+
+# hipcc merges the loop's `break` exits and its back edge into ONE block steered by an SGPR mask; the address arithmetic of
+# the loop-head group may then sit in registers that group's own loads are about to overwrite
+ASM_MERGED = """_ZN3isk11scan_kernelILi1ELb0ELi8ELi0ELb1EEEvNS_10ScanParamsE:
+	;;#ASMSTART
+	s_nop 4
+	global_load_dwordx4 v[2:5], v1, s[0:1] offset:0 nt
+	;;#ASMEND
+	s_branch .LBB0_5
+.LBB0_4:
+	{in_exit_block}
+	s_and_b64 vcc, exec, s[0:1]
+	s_cbranch_vccnz .LBB0_9
+.LBB0_5:
+	v_lshlrev_b64 v[6:7], 12, v[40:41]
+	;;#ASMSTART
+	s_nop 4
+	global_load_dwordx4 v[6:9], v1, s[2:3] offset:0 nt
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_xor_b32_e32 v10, v2, v20
+	s_cbranch_vccnz .LBB0_4
+	;;#ASMSTART
+	s_nop 4
+	global_load_dwordx4 v[2:5], v1, s[0:1] offset:0 nt
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_xor_b32_e32 v11, v6, v20
+	s_branch .LBB0_4
+.LBB0_9:
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def run_merged(tmp_path, in_exit_block="s_nop 0"):
+    a, r = tmp_path / "m.s", tmp_path / "m.res"
+    a.write_text(ASM_MERGED.format(in_exit_block=in_exit_block))
+    r.write_text(RES.format(scratch=0, spill=0))
+    p = subprocess.run([sys.executable, TOOL, str(a), str(r)], capture_output=True, text=True)
+    return p.returncode, p.stdout
+
+
+def test_accepts_address_arithmetic_in_the_loop_head_groups_own_registers(tmp_path):
+    rc, out = run_merged(tmp_path)
+    assert rc == 0 and "3 asm load groups in 1 kernels" in out, out
+
+
+def test_still_rejects_a_touch_in_the_merged_exit_block(tmp_path):
+    # on the `break` path the loop-head group is in flight until .LBB0_9: reading v7 in the shared exit block is a real hazard
+    rc, out = run_merged(tmp_path, in_exit_block="v_mov_b32_e32 v30, v7")
+    assert rc == 1 and "touches a destination of the load group" in out, out

@@ -131,6 +131,10 @@ def audit_loads(name, ins):
                     break
                 vector = not text.startswith("s_")
                 if vregs(text) & dests and (not exec0 or text.startswith(("v_readlane", "v_readfirstlane"))) and vector:
+                    if i < start and not any(ins[j][0].endswith(":") or ins[j][0].startswith(("s_branch", "s_cbranch", "s_endpgm")) for j in range(i, start)):
+                        # straight-line code that runs INTO the group we started from (its address arithmetic, in registers the
+                        # group's own loads are about to overwrite): the same impossible return as in the case above
+                        break
                     bad.append(f"{name}: `{text}` (#{i}) touches a destination of the load group at #{start} before its counted wait")
                     break
                 bm = re.match(r"(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", text)
