@@ -137,3 +137,68 @@ def test_large_batch_under_default_thresholds(hip_engine, nbytes, metric):
             np.testing.assert_array_equal(g, e, err_msg="valu " + name)
     finally:
         t.drop()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# k <= 512 on the matrix cores is ONE pass with self-tightening thresholds (MODE_SELF); larger k and the option
+# self_tighten=0 take threshold levels + picks.  Everything above ran the default; the level design stays covered here, and
+# the two must agree with each other and with the oracle where the single pass is most exposed: clustered codes (big tie
+# classes, thresholds that collapse to 0 within the first steps), planted duplicates, k at both ends of its range.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def forced_levels(forced):
+    forced.set_option("self_tighten", 0)
+    yield forced
+    forced.set_option("self_tighten", 1)
+
+
+@pytest.mark.parametrize("n,k,nq", [(70000, 10, 40), (300000, 100, 17)])
+def test_hamming64_random_with_levels(forced_levels, n, k, nq):
+    parity.test_hamming64_random_vs_oracle(forced_levels, n, k, nq)
+
+
+def test_nphd_mixed_lengths_with_levels(forced_levels):
+    parity.test_nphd_mixed_lengths_vs_oracle(forced_levels)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_fuzz_sequences_with_levels(forced_levels, seed):
+    fuzz.test_random_operation_sequences(forced_levels, seed)
+
+
+@pytest.mark.parametrize("nbytes,k", [(8, 1), (8, 10), (8, 512), (16, 100), (29, 37)])
+def test_self_tightening_pass_equals_levels_and_oracle(hip_engine, nbytes, k):
+    rng = np.random.default_rng(977 + nbytes + k)
+    n, nq = 262_144 + 77, 96
+    mw = (nbytes + 7) // 8
+    # a third of the rows are noisy copies of 12 base codes (0-3 flipped bits), the rest random
+    words = parity._rand_words(rng, n, mw, nbytes)
+    bases = parity._rand_words(rng, 12, mw, nbytes)
+    clustered = rng.random(n) < 0.33
+    pick = rng.integers(0, 12, size=n)
+    noisy = bases[pick].copy()
+    for _ in range(3):      # up to three flipped bits per copy (a flip beyond the code's length is masked away again)
+        noisy[:, 0] ^= (rng.random(n) < 0.5).astype(np.uint64) << rng.integers(0, 64, size=n).astype(np.uint64)
+    words[clustered] = noisy[clustered]
+    words = fuzz._mask(words, nbytes)
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(11)
+    q = np.concatenate([bases, words[rng.integers(0, n, size=nq - 12 - 30)], parity._rand_words(rng, 30, mw, nbytes)])
+    t = hip_engine.open_table(0, 1, nbytes)
+    try:
+        t.add(keys, words)
+        before = hip_engine.stats()
+        single_pass = t.search(q, None, k)
+        after = hip_engine.stats()
+        assert after["mfma_launches"] > before["mfma_launches"] and after["level_launches"] == before["level_launches"], "not the single pass"
+        hip_engine.set_option("self_tighten", 0)
+        try:
+            levels = t.search(q, None, k)
+            assert hip_engine.stats()["level_launches"] > after["level_launches"], "not the level design"
+        finally:
+            hip_engine.set_option("self_tighten", 1)
+        exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=nbytes)
+        for g, l, e, name in zip(single_pass, levels, exp, ("keys", "hamming", "prefix_bits", "count")):
+            np.testing.assert_array_equal(g, e, err_msg="single pass: " + name)
+            np.testing.assert_array_equal(l, e, err_msg="levels: " + name)
+    finally:
+        t.drop()
