@@ -95,6 +95,9 @@ typedef struct isccsearch_stats {
     uint64_t level_pair_words;
     uint64_t level_mfma_launches;
     double   level_ms;
+    /* batches whose single self-tightening pass (k <= 512 on the matrix cores) overflowed a candidate list and were answered
+       again with threshold levels, which prune after every level, before any query took the per-query exact fallback */
+    uint64_t self_retries;
 } isccsearch_stats;
 
 /* Engine lifetime.  One handle drives one GPU (one process per GPU). */

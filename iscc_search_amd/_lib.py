@@ -59,6 +59,7 @@ class Stats(ctypes.Structure):
         ("level_pair_words", ctypes.c_uint64),
         ("level_mfma_launches", ctypes.c_uint64),
         ("level_ms", ctypes.c_double),
+        ("self_retries", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -421,6 +421,7 @@ struct Batch {
     size_t sel_lds = 0;
     bool multi = false;
     bool mark_overflow = false;         // search_device_async: overflowed queries report COUNT_OVERFLOW instead of being fixed here
+    bool allow_self = true, used_self = false;   // the single self-tightening pass, and whether a job of this batch took it
     std::vector<Job> jobs;
 
     Batch(H* h_, Table& t_, uint32_t nq_, uint32_t qbytes_, uint32_t k_, isk::Record* out, uint32_t* out_cnt)
@@ -479,6 +480,8 @@ struct Batch {
 
     // hq: host query words [nq][max_words]
     int begin(const uint64_t* hq) {
+        jobs.clear();
+        used_self = false;
         tq = h->tq;
         nq_pad = (nq + tq - 1) / tq * tq;
         groups = nq_pad / tq;
@@ -600,7 +603,8 @@ struct Batch {
             //    tile could see a new threshold -- before any update reaches them, and fresh thresholds must be read past the
             //    per-XCD L2s (sc1 / glc), where 8 192 waves hammering one line serialise: measured 0.24-0.53 ms for 1-8
             //    queries over 100 M rows against 0.10 ms for the collect pass of the level design.)
-            const bool self = h->self_tighten && k <= h->self_max_k && use_mfma(s.n);
+            const bool self = allow_self && h->self_tighten && k <= h->self_max_k && use_mfma(s.n);
+            used_self = used_self || self;
             const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(self ? h->self_boot_rows : h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
             isk::BootParams bp{};
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
@@ -792,6 +796,15 @@ struct Batch {
         return 0;
     }
 
+    // The single pass never prunes its candidate lists; when one overflows (huge tie classes, clustered codes) the WHOLE batch
+    // is answered again by the level design, which prunes after every level -- one more batch pass instead of one exact
+    // full-table fallback per flagged query.  What is still flagged afterwards goes to fix().
+    int retry_with_levels(const uint64_t* hq) {
+        allow_self = false;
+        h->stats.self_retries += 1;
+        return begin(hq);
+    }
+
     // everything up to final device-resident results (used by the device variant and multi-segment tables)
     int run_to_device(const uint64_t* hq) {
         int rc;
@@ -799,6 +812,11 @@ struct Batch {
         if (jobs.empty()) return 0;
         if ((rc = copy_flags())) return rc;
         HIPOK(hipStreamSynchronize(h->stream));
+        if (used_self && any_flag()) {
+            if ((rc = retry_with_levels(hq))) return rc;
+            if ((rc = copy_flags())) return rc;
+            HIPOK(hipStreamSynchronize(h->stream));
+        }
         if (any_flag() && (rc = fix())) return rc;
         return merge();
     }
@@ -1467,6 +1485,11 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             // the per-segment lists must be complete before they are merged
             if ((rc = batch.copy_flags())) return rc;
             HIPOK(hipStreamSynchronize(h->stream));
+            if (batch.used_self && batch.any_flag()) {
+                if ((rc = batch.retry_with_levels(hq.data()))) return rc;
+                if ((rc = batch.copy_flags())) return rc;
+                HIPOK(hipStreamSynchronize(h->stream));
+            }
             if (batch.any_flag() && (rc = batch.fix())) return rc;
             if ((rc = batch.merge())) return rc;
             if ((rc = copy_results())) return rc;
@@ -1476,6 +1499,12 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             if (!one_copy && (rc = batch.copy_flags())) return rc;
             if ((rc = copy_results())) return rc;
             HIPOK(hipStreamSynchronize(h->stream));
+            if (!batch.jobs.empty() && batch.used_self && batch.any_flag()) {
+                if ((rc = batch.retry_with_levels(hq.data()))) return rc;
+                if (!one_copy && (rc = batch.copy_flags())) return rc;
+                if ((rc = copy_results())) return rc;
+                HIPOK(hipStreamSynchronize(h->stream));
+            }
             if (!batch.jobs.empty() && batch.any_flag()) {
                 if ((rc = batch.fix())) return rc;
                 if ((rc = copy_results())) return rc;

@@ -250,7 +250,10 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     for (; step < nsteps; step += stride, ++trip) {
         const uint64_t ns = step + stride < nsteps ? step + stride : step;
         float fresh[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool refresh_now = refresh && (trip & refresh_mask) == 0;      // (MODE_SELF only: `refresh` is false otherwise)
+        // (a wave's first steps always look: all waves start under the bootstrap threshold at once, and until the first update
+        //  arrives every row within it is appended -- a 4 M-row table would be scanned whole under it at 16 steps per look)
+        const bool look = trip < 8 || (trip & refresh_mask) == 0;
+        const bool refresh_now = refresh && look;                             // (MODE_SELF only: `refresh` is false otherwise)
         if constexpr (MODE == MODE_SELF) {
             if (refresh_now) {
 #pragma unroll
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
         if constexpr (MODE == MODE_SELF) {
             if (refresh_now) *reinterpret_cast<float4*>(lthr + fresh_at) = make_float4(fresh[0], fresh[1], fresh[2], fresh[3]);
             if constexpr (ASYNC) {
-                if ((trip & refresh_mask) == refresh_mask) pend.complete(p, q0, lpop);
+                if (look) pend.complete(p, q0, lpop);
             }
         }
     }
