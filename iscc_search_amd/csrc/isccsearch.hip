@@ -167,6 +167,7 @@ struct isccsearch_handle {
     // k <= 64 on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
     // every launch of the chain costs ~35 us of ramp, prologue and tail, a step of 100 M rows had seven of them
     bool self_tighten = true;
+    uint32_t candidate_cap = 16384;   // floor of the per-query candidate buffer (entries); tests shrink it to reach the overflow paths
     uint32_t self_refresh_steps = 1;  // steps of a full chunk between two looks at the live thresholds (power of two)
     uint32_t self_max_k = 512;        // the unpruned lists hold ~17 k entries + the first steps' flood: see the cap in Batch::begin
                                       // (100 M rows, k = 100 / 256 / 512: 3.80 / 4.52 / 6.04 ms against 4.60 / 5.35 / 7.37 with levels)
@@ -500,7 +501,7 @@ struct Batch {
             HIPOK(hipMemsetAsync(d_out_cnt, 0, nq * sizeof(uint32_t), h->stream));
             return 0;
         }
-        cap = std::max<uint32_t>(16384, 16 * k);
+        cap = std::max<uint32_t>(h->candidate_cap, 16 * k);
         // the self-tightening pass never prunes: ~17 k entries per query over 100 M rows (+ the flood of the first steps)
         if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0) cap = std::max<uint32_t>(cap, 48 * k);
         multi = jobs.size() > 1;
@@ -955,6 +956,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
         if (value < 1 || value > 64 || (value & (value - 1))) return fail(-EINVAL, "self_refresh_steps must be a power of two in 1..64");
         h->self_refresh_steps = (uint32_t)value; return 0;
     }
+    if (!strcmp(name, "candidate_cap")) { if (value < 64 || value > (1 << 22)) return fail(-EINVAL, "candidate_cap must be 64..4194304"); h->candidate_cap = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_max_k")) { if (value < 1 || value > 512) return fail(-EINVAL, "self_max_k must be 1..512"); h->self_max_k = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }

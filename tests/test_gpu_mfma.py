@@ -202,3 +202,36 @@ def test_self_tightening_pass_equals_levels_and_oracle(hip_engine, nbytes, k):
             np.testing.assert_array_equal(l, e, err_msg="levels: " + name)
     finally:
         t.drop()
+
+
+def test_an_overflowed_single_pass_is_answered_again_by_the_levels(hip_engine):
+    """
+    The single pass never prunes its candidate lists (~k ln(n / sample) entries + ties + the first steps' flood).  With the
+    buffer shrunk to 480 entries and a 256-row bootstrap sample (every wave starts under a threshold that ~4 % of the rows
+    pass) it overflows where the level design, which prunes after every level, still fits: the batch must come back exact,
+    through ONE retry and without the per-query exact fallback.
+    """
+    rng = np.random.default_rng(5150)
+    n, nq, k = 300_000, 64, 10
+    words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
+    q = rng.integers(0, 2**64, size=(nq, 1), dtype=np.uint64)
+    t = hip_engine.open_table(0, 1, 8)
+    try:
+        t.add(keys, words)
+        hip_engine.set_option("candidate_cap", 256)
+        hip_engine.set_option("self_boot_rows", 256)
+        try:
+            before = hip_engine.stats()
+            got = t.search(q, None, k)
+            after = hip_engine.stats()
+        finally:
+            hip_engine.set_option("candidate_cap", 16384)
+            hip_engine.set_option("self_boot_rows", 65536)
+        assert after["self_retries"] == before["self_retries"] + 1, "the single pass was expected to overflow its lists"
+        assert after["fallback_queries"] == before["fallback_queries"], "the level design was expected to fit its lists"
+        exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+        for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+            np.testing.assert_array_equal(g, e, err_msg=name)
+    finally:
+        t.drop()
