@@ -86,7 +86,7 @@ typedef struct isccsearch_stats {
     uint32_t queries_per_pass;/* T_q: queries held in SGPRs per streaming pass                */
     uint32_t compute_units;   /* CUs of the device                                            */
     uint64_t freq_builds;     /* document-frequency columns (re)built by isccsearch_get_freq  */
-    uint64_t mfma_launches;   /* scan launches (levels + collect) that ran on the matrix cores (FP4)         */
+    uint64_t mfma_launches;   /* scan launches (single pass, levels, collect) that ran on the matrix cores (FP4) */
     uint64_t mfma_pair_words; /* (row, query, 64-bit word) triples those launches scored: 128 operations each   */
     uint64_t scan_pair_words; /* (row, REAL query, word) triples of the collect launches counted in scan_launches / scan_ms */
     uint64_t scan_mfma_launches; /* how many of scan_launches ran on the matrix cores                          */
@@ -107,7 +107,10 @@ const char* isccsearch_last_error(void);
 
 /* Options: "mfma" (0|1, default 1: batches of >= "mfma_min_queries" (17) queries over >= "mfma_min_rows" (65 536) rows are
  * scanned on the matrix cores -- bits as FP4 0/+-1, exact f32 sums, csrc/mfma_scan.hip -- instead of XOR + popcount;
- * "mfma_level_growth" (4): growth of the threshold levels there); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
+ * "self_tighten" (0|1, default 1): for k <= "self_max_k" (512) that scan is ONE pass whose thresholds tighten themselves,
+ * bootstrapped from "self_boot_rows" (65 536) rows and looking at the live thresholds every "self_refresh_steps" (1) steps,
+ * instead of threshold levels growing by "mfma_level_growth" (4)); "candidate_cap" (16 384: floor of the per-query candidate
+ * buffer, in entries); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
  * (0|1: time every collect-scan launch with HIP events, read back through isccsearch_stats_get), "stretch_mb" (XOR + popcount
  * kernel: rows per collect launch, in MB of codes, when several query groups share a launch: they then read the stretch from the
  * caches instead of HBM; default 128, 0 = one streaming pass per group), "fold_tau" (whole 64-bit codes: query groups whose
