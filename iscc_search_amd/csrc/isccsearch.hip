@@ -154,7 +154,9 @@ struct isccsearch_handle {
     bool profile = false;
     bool nontemporal = true;
     uint32_t blocks_per_cu = 8;    // scan grid = CUs x this (per query group)
-    uint64_t boot_rows = 4096;     // rows of the threshold bootstrap (exact histogram per query)
+    uint64_t boot_rows = 65536;    // rows of the threshold bootstrap of the level design (4 096 exact + the rest counted under that
+                                   // cut; wide blocks for small batches): one level launch + pick less than with 4 096 rows
+                                   // (100 M x 64-bit: 8 queries 0.231 against 0.252 ms, 4 queries at k = 100 0.286 against 0.354)
     uint64_t level_growth = 8;     // each threshold level streams this many times the rows seen so far
     bool repick = true;            // re-derive the threshold after every collect stretch but the last
     uint32_t fold_tau = 11;        // 64-bit codes: groups whose thresholds are all <= this take the folded fast path (0: off)

@@ -169,7 +169,7 @@ def test_fuzz_sequences_with_levels(forced_levels, seed):
 @pytest.mark.parametrize("nbytes,k", [(8, 1), (8, 10), (8, 512), (16, 100), (29, 37)])
 def test_self_tightening_pass_equals_levels_and_oracle(hip_engine, nbytes, k):
     rng = np.random.default_rng(977 + nbytes + k)
-    n, nq = 262_144 + 77, 96
+    n, nq = 1_000_000 + 77, 96   # beyond 8 x the 65 536-row bootstrap sample: the level design needs a level before its collect pass
     mw = (nbytes + 7) // 8
     # a third of the rows are noisy copies of 12 base codes (0-3 flipped bits), the rest random
     words = parity._rand_words(rng, n, mw, nbytes)
