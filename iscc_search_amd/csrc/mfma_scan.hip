@@ -26,8 +26,15 @@
 // SIMD's issue port (~50 cycles per 1 024 pairs and word against 32 of matrix-pipe time); the XOR + popcount kernel needs
 // ~290.  Rows cross the memory system once per chunk of up to 1 024 queries.  Measured numbers: DESIGN.md section 4.
 //
-// Built with -mllvm -amdgpu-mfma-vgpr-form=1: hipcc otherwise puts the accumulators in AGPRs and pays one
-// v_accvgpr_read per result before the fold (16 extra VALU instructions per tile and group).
+// Modes (scan_params.hip.h): MODE_COLLECT (range-limited searches: a given threshold), MODE_BOTH / MODE_STRETCH (the threshold
+// levels and the collect pass of the level design: append + histogram, picks between launches) and MODE_SELF -- ONE launch
+// over all rows whose thresholds tighten themselves: the live thresholds are re-read from global memory once per step, every
+// candidate is counted per distance, and the lane that proves "k rows within t" lowers the threshold (see Pending, emit_self,
+// lower_threshold).  The default for k <= 512.
+//
+// Built with -mllvm -amdgpu-mfma-vgpr-form=1 -ffinite-math-only: hipcc otherwise puts the accumulators in AGPRs and pays one
+// v_accvgpr_read per result before the fold (16 extra VALU instructions per tile and group), and canonicalises the inputs of
+// every 2-input fminf (two v_max per group: the values are small integers, never NaN).
 #include "mfma_scan.h"
 
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// scan_params.hip.h -- what the scan kernels of kernels.hip.h (XOR + popcount on the VALU) and of mfma_scan.hip (int8
+// scan_params.hip.h -- what the scan kernels of kernels.hip.h (XOR + popcount on the VALU) and of mfma_scan.hip (FP4 on the
 // matrix cores) share: constants, the launch parameters and the candidate append.
 #pragma once
 
