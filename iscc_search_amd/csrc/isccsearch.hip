@@ -166,8 +166,8 @@ struct isccsearch_handle {
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
-    // k <= 64 on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
-    // every launch of the chain costs ~35 us of ramp, prologue and tail, a step of 100 M rows had seven of them
+    // k <= self_max_k on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
+    // every launch of that chain costs ~35 us of ramp, prologue and tail, and a step of 100 M rows had seven of them
     bool self_tighten = true;
     uint32_t candidate_cap = 16384;   // floor of the per-query candidate buffer (entries); tests shrink it to reach the overflow paths
     uint32_t self_refresh_steps = 1;  // steps of a full chunk between two looks at the live thresholds (power of two)
@@ -1851,13 +1851,24 @@ static int merge_device_impl(isccsearch_handle* h, uint32_t n_lists, uint32_t nq
     // The merge writes its {records | counts} straight into ONE pinned host block (page-locked memory is mapped into the
     // device's address space): 240 bytes per query cross PCIe as the kernel's own stores, and the host needs a single
     // synchronisation -- no device->host copies to launch (each cost ~25 us of queue hand-over after the kernel).
+    // (Blocks above DIRECT_RESULT_BYTES -- large k x many queries -- go through device memory and two DMA copies as before.)
     const size_t rec_bytes = (size_t)nq * k * sizeof(isk::Record);
+    const bool direct = rec_bytes + (size_t)nq * sizeof(uint32_t) <= DIRECT_RESULT_BYTES;
     if ((rc = h->p_block.ensure(rec_bytes + (size_t)nq * sizeof(uint32_t)))) return rc;
+    if (!direct) {
+        if ((rc = h->d_final.ensure((size_t)nq * k))) return rc;
+        if ((rc = h->d_outcnt.ensure(nq))) return rc;
+    }
     isk::MergeParams mp{static_cast<const unsigned char*>(d_records), static_cast<const unsigned char*>(d_counts),
-                        list_stride, count_stride, reinterpret_cast<isk::Record*>(h->p_block.p),
-                        reinterpret_cast<uint32_t*>(h->p_block.p + rec_bytes), n_lists, nq, k};
+                        list_stride, count_stride,
+                        direct ? reinterpret_cast<isk::Record*>(h->p_block.p) : h->d_final.p,
+                        direct ? reinterpret_cast<uint32_t*>(h->p_block.p + rec_bytes) : h->d_outcnt.p, n_lists, nq, k};
     hipLaunchKernelGGL(isk::merge_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, mp);
     HIPOK(hipGetLastError());
+    if (!direct) {
+        HIPOK(hipMemcpyAsync(h->p_block.p, h->d_final.p, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipMemcpyAsync(h->p_block.p + rec_bytes, h->d_outcnt.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    }
     HIPOK(hipStreamSynchronize(h->stream));
     unpack_records(reinterpret_cast<const isk::Record*>(h->p_block.p), reinterpret_cast<const uint32_t*>(h->p_block.p + rec_bytes), nq, k, key_words,
                    nullptr, out_keys, out_hamming, out_prefix_bits, out_count);
