@@ -271,8 +271,8 @@ def main():
         return el, st
 
     # Clock settle, before the W warm-up steps and outside every timing: a fresh process finds the GPU in its idle power
-    # state, and the matrix-core kernel of this step takes ~15 steps (~50 ms) to reach its steady clock (3.35 -> 2.80 ms per
-    # launch in profiles/r02_kernel_stats_mfma.csv: min / max over the first 14 launches).  A serving process is never in that
+    # state, and the matrix-core kernel of this step takes ~15 steps (~50 ms) to reach its steady clock (3.46 -> 2.86 ms per
+    # launch in profiles/r02_kernel_stats_mfma.csv: first / fastest launch of a fresh process).  A serving process is never in that
     # state for longer than its first request, so the bench runs untimed steps until five consecutive steps are within 1 % of
     # the five before them (at most `--settle-steps`, the same number on every rank), and says how many it took.
     settle_steps = 0
