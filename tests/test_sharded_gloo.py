@@ -185,3 +185,36 @@ def test_shard_arithmetic():
             assert max(sizes) - min(sizes) <= 1
     assert block_bytes(3, 5) == (3 * 5 * RECORD_BYTES, 3 * 5 * RECORD_BYTES + 16)
     assert {shard_of_key(k, 8) for k in range(1000)} == set(range(8))
+
+
+def test_one_shard_takes_the_direct_entry_point_when_the_ops_offer_one():
+    """
+    With a single rank and no forced collective ``ShardedTable`` hands the whole search to ``ops.search_single`` (the product's
+    host entry point: no result block, no merge launch); ops without it -- the oracle stand-in above -- keep the block + merge
+    path.  Both must give the same answer.
+    """
+    keys, words, lens, q, qlens = _dataset(0)
+    table = OracleTable(0, 1, 8)
+    table.add(keys, words, None)
+
+    class DirectOps(OracleShardOps):
+        calls = 0
+
+        def search_single(self, q_words, q_nbytes, k, max_hamming=None):
+            DirectOps.calls += 1
+            block = OracleShardOps.local_search(self, q_words, q_nbytes, k, max_hamming)
+            return OracleShardOps.merge(self, block, 1, q_words.shape[0], k)
+
+        def local_search(self, *a, **kw):       # the shortcut must not build a block
+            raise AssertionError("local_search called although search_single is offered")
+
+    direct = ShardedTable(DirectOps(table))
+    assert direct.world_size == 1
+    got = direct.search(q, qlens, 12)
+    got_within = direct.search_within(q, qlens, 12, 1)
+    assert DirectOps.calls == 2
+    plain = ShardedTable(OracleShardOps(table))
+    for a, b in zip(got, plain.search(q, qlens, 12)):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(got_within, plain.search_within(q, qlens, 12, 1)):
+        np.testing.assert_array_equal(a, b)
