@@ -69,3 +69,13 @@ def test_product_package_never_imports_the_oracle():
                     src = f.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
                 assert "liboracle" not in src, fn
+
+
+def test_plain_c_client_compiles_and_links_against_the_header(tmp_path):
+    """tests/abi_client.c is the ABI as a C host sees it (the GPU tier runs it: tests/test_gpu_abi_client.py)."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "iscc_search_amd", "csrc")
+    subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "abi_client.c"), "-o", str(tmp_path / "abi_client"), "-L", csrc, "-lisccsearch_hip",
+                    "-Wl,-rpath," + csrc], check=True)
