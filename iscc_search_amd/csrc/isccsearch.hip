@@ -26,6 +26,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "../../include/isccsearch.h"
@@ -828,10 +829,32 @@ struct Batch {
     }
 };
 
+void unpack_range(const isk::Record* rec, const uint32_t* cnt, uint32_t q_begin, uint32_t q_end, uint32_t k, int key_words,
+                  const uint32_t* dest_index, uint64_t* out_keys, uint32_t* out_h, uint16_t* out_p, uint32_t* out_c);
+
+// Records -> the caller's arrays.  A large block (k in the hundreds x a full batch: 10^5..10^6 records, 0.1-0.5 ms on one core,
+// up to 14 % of such a step) is split by query over a few threads; the usual block (1 024 x 10 records) is done in place.
 void unpack_records(const isk::Record* rec, const uint32_t* cnt, uint32_t nq, uint32_t k, int key_words,
                     const uint32_t* dest_index /*nullable: original query index per row*/,
                     uint64_t* out_keys, uint32_t* out_h, uint16_t* out_p, uint32_t* out_c) {
-    for (uint32_t q = 0; q < nq; ++q) {
+    const uint64_t records = (uint64_t)nq * k;
+    const uint32_t hw = std::thread::hardware_concurrency();
+    const uint32_t threads = records < (1u << 17) ? 1u : std::min<uint32_t>({8u, hw ? hw : 1u, nq});
+    if (threads <= 1) {
+        unpack_range(rec, cnt, 0, nq, k, key_words, dest_index, out_keys, out_h, out_p, out_c);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; ++t)
+        pool.emplace_back(unpack_range, rec, cnt, (uint32_t)((uint64_t)nq * t / threads), (uint32_t)((uint64_t)nq * (t + 1) / threads), k, key_words,
+                          dest_index, out_keys, out_h, out_p, out_c);
+    unpack_range(rec, cnt, 0, (uint32_t)((uint64_t)nq / threads), k, key_words, dest_index, out_keys, out_h, out_p, out_c);
+    for (auto& th : pool) th.join();
+}
+
+void unpack_range(const isk::Record* rec, const uint32_t* cnt, uint32_t q_begin, uint32_t q_end, uint32_t k, int key_words,
+                  const uint32_t* dest_index, uint64_t* out_keys, uint32_t* out_h, uint16_t* out_p, uint32_t* out_c) {
+    for (uint32_t q = q_begin; q < q_end; ++q) {
         const uint32_t dq = dest_index ? dest_index[q] : q;
         const uint32_t c = cnt[q] == isk::COUNT_OVERFLOW ? 0 : std::min(cnt[q], k);
         out_c[dq] = cnt[q] == isk::COUNT_OVERFLOW ? isk::COUNT_OVERFLOW : c;
