@@ -52,6 +52,9 @@ typedef const __attribute__((address_space(3))) float* lds_thr_ptr;
 #define ISK_MFMA_TILES_W4 2
 #endif
 template <int W> constexpr int mfma_tiles() { return W == 4 ? ISK_MFMA_TILES_W4 : 2; }
+#ifndef ISK_SCALAR_STEPS_FROM_W
+#define ISK_SCALAR_STEPS_FROM_W 2     // experiment switch: code widths (in 64-bit words) from which the step number is kept scalar
+#endif
 constexpr int MBLOCK = 256;           // 4 waves; a chunk's LDS image is <= 40 KB, so LDS admits four blocks per CU
 // Registers decide: the rare emit path (both accumulator sets live + 64-bit row numbers) peaks at 130-175 VGPRs, i.e. three
 // waves per SIMD for W <= 3 and two for W = 4.  Forcing four (128 VGPRs) spilled to scratch; the prototype measured
@@ -157,7 +160,13 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     const uint64_t first = p.row_begin / (32 * MT);                         // row_begin is a multiple of 64
     const uint64_t nsteps = (p.n_rows + 32 * MT - 1) / (32 * MT);           // the last step may be partial
     const uint64_t stride = (uint64_t)gridDim.x * (MBLOCK / 64);
-    uint64_t step = first + (uint64_t)blockIdx.x * (MBLOCK / 64) + wave;
+    // W >= 2: the wave number is read as a SCALAR, so that the step number and the row addresses live on the scalar unit
+    // (scalar-base loads) instead of ~14 vector instructions of 64-bit address arithmetic per step.  Same box, A/B: 128-bit
+    // 4.586 against 4.605 ms per 1 024 queries and 0.57-0.59 against 0.615 ms per 64; 256-bit 9.20 against 9.36 and no change
+    // at 64 queries.  Not for 64-bit codes: nothing at 1 024 queries and 17-64 queries measured 15-20 % slower.
+    constexpr bool SCALAR_STEPS = ISK_SCALAR_STEPS_FROM_W <= W;
+    const uint32_t wave_u = SCALAR_STEPS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) : wave;
+    uint64_t step = first + (uint64_t)blockIdx.x * (MBLOCK / 64) + wave_u;
     if (step >= nsteps) return;
     const uint64_t last_row = p.n_rows - 1;
 
@@ -242,11 +251,24 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     const float* lt = lthr + r;
     auto row_of = [&](uint64_t st, int t) { const uint64_t row = (st * MT + t) * 32 + r; return row <= last_row ? row : last_row; };
 
+    // the rows of step `st`: lane (r, h) of tile t reads dword h of row st * 32 MT + 32 t + r.  SCALAR_STEPS: a uniform base plus a
+    // constant per-lane offset; only the table's last step can be partial and clamps per lane as the general form does
+    const uint32_t lane_dword = r * 2 + h;
+    auto load_rows = [&](uint64_t st, uint32_t (&dst)[MT][W]) {
+        if (SCALAR_STEPS && (st + 1) * (32 * MT) <= p.n_rows) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int w = 0; w < W; ++w) dst[t][w] = (col32[w] + st * (64 * MT) + t * 64)[lane_dword];
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int w = 0; w < W; ++w) dst[t][w] = col32[w][row_of(st, t) * 2 + h];
+        }
+    };
     uint32_t x[MT][W], xn[MT][W];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int w = 0; w < W; ++w) x[t][w] = col32[w][row_of(step, t) * 2 + h];
+    load_rows(step, x);
     // MODE_SELF: wave w keeps the block's copy of thresholds [256 w, 256 w + 256) fresh -- requested here, written to LDS
     // after the group loop, picked up by all four waves from their next step on (a stale threshold is only a looser one)
     const uint32_t fresh_at = wave * 256 + lane * 4;
@@ -267,10 +289,7 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
                 for (int i = 0; i < 4; ++i) fresh[i] = live_threshold(p.thr_live + q0 + fresh_at + i);
             }
         }
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int w = 0; w < W; ++w) xn[t][w] = col32[w][row_of(ns, t) * 2 + h];     // next step's rows, in flight during this one
+        load_rows(ns, xn);                                                          // next step's rows, in flight during this one
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
