@@ -113,7 +113,8 @@ const char* isccsearch_last_error(void);
  * buffer, in entries); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
  * (0|1: time every collect-scan launch with HIP events, read back through isccsearch_stats_get), "stretch_mb" (XOR + popcount
  * kernel: rows per collect launch, in MB of codes, when several query groups share a launch: they then read the stretch from the
- * caches instead of HBM; default 128, 0 = one streaming pass per group), "fold_tau" (whole 64-bit codes: query groups whose
+ * caches instead of HBM; default 128, 0 = one streaming pass per group; matrix-core launches whose query chunks share the rows take
+ * "mfma_stretch_factor" (3) times that), "fold_tau" (whole 64-bit codes: query groups whose
  * thresholds are all <= this take the folded 3.5-op fast path; default 11, 0 = never); tuning: "blocks_per_cu", "boot_rows",
  * "level_growth", "repick".  "nontemporal" accepts only 1 (the only variant built). */
 int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);

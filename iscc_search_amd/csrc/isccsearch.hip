@@ -162,6 +162,7 @@ struct isccsearch_handle {
     bool repick = true;            // re-derive the threshold after every collect stretch but the last
     uint32_t fold_tau = 11;        // 64-bit codes: groups whose thresholds are all <= this take the folded fast path (0: off)
     uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
+    uint64_t mfma_stretch_factor = 3;               // ... times this on the matrix cores, when several CHUNKS of queries share them
     // large batches: the scan as an FP4 matrix-core contraction (mfma_scan.hip) instead of XOR + popcount on the VALU
     bool mfma = true;
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
@@ -555,7 +556,11 @@ struct Batch {
                 uint64_t stretch = s.n;
                 // (the MFMA kernel reads the rows once per CHUNK of up to 1 024 / W queries: one chunk has nothing to share)
                 const bool shared = use_mfma(s.n - from) ? nq_pad > isk::mfma_groups_per_chunk((int)j.W, nq_pad) * 32 : groups > 1;
-                if (shared && h->stretch_bytes) stretch = std::max<uint64_t>(tile_rows, h->stretch_bytes / (8 * j.W) / tile_rows * tile_rows);
+                // (matrix-core launches: the chunks' blocks are all resident and walk a stretch in step, so three times the size
+                //  still shares it in the caches and every launch saved is ~30 us of ramp and tail.  Same box, factor 1 / 2 / 3 / 4:
+                //  256-bit 9.31 / 8.90 / 8.79 / 8.72 ms, 128-bit 4.67 / 4.55 / 4.53 / 4.52, 192-bit 7.88 / 7.74 / 7.67 / 7.99)
+                const uint64_t stretch_bytes = use_mfma(s.n - from) ? h->stretch_bytes * h->mfma_stretch_factor : h->stretch_bytes;
+                if (shared && stretch_bytes) stretch = std::max<uint64_t>(tile_rows, stretch_bytes / (8 * j.W) / tile_rows * tile_rows);
                 for (uint64_t a = from; a < s.n;) {
                     const uint64_t b = s.n - a <= stretch + stretch / 4 ? s.n : a + stretch;     // no sliver at the end
                     sp.row_begin = a;
@@ -973,6 +978,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "fold")) { h->fold_tau = value ? 11 : 0; return 0; }   // shorthand kept from the experiments
     if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(-EINVAL, "blocks_per_cu must be 1..64"); h->blocks_per_cu = (uint32_t)value; return 0; }
     if (!strcmp(name, "boot_rows")) { if (value < 256 || value > 65536) return fail(-EINVAL, "boot_rows must be 256..65536"); h->boot_rows = (uint64_t)value; return 0; }
+    if (!strcmp(name, "mfma_stretch_factor")) { if (value < 1 || value > 64) return fail(-EINVAL, "mfma_stretch_factor must be 1..64"); h->mfma_stretch_factor = (uint64_t)value; return 0; }
     if (!strcmp(name, "stretch_mb")) { if (value < 0 || value > 65536) return fail(-EINVAL, "stretch_mb must be 0..65536"); h->stretch_bytes = (uint64_t)value << 20; return 0; }
     if (!strcmp(name, "repick")) { h->repick = value != 0; return 0; }
     if (!strcmp(name, "fold_tau")) { if (value < 0 || value > 32) return fail(-EINVAL, "fold_tau must be 0..32"); h->fold_tau = (uint32_t)value; return 0; }
