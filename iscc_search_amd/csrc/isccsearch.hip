@@ -171,6 +171,7 @@ struct isccsearch_handle {
     // k <= self_max_k on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
     // every launch of that chain costs ~35 us of ramp, prologue and tail, and a step of 100 M rows had seven of them
     bool self_tighten = true;
+    bool boot_multi = true;           // large batches: boot_multi_kernel (four queries per block share the sample's row loads)
     uint32_t candidate_cap = 16384;   // floor of the per-query candidate buffer (entries); tests shrink it to reach the overflow paths
     uint32_t self_refresh_steps = 1;  // steps of a full chunk between two looks at the live thresholds (power of two)
     uint32_t self_max_k = 512;        // the unpruned lists hold ~17 k entries + the first steps' flood: see the cap in Batch::begin
@@ -624,8 +625,19 @@ struct Batch {
             bp.thr = self ? h->d_thr.p : nullptr;
             bp.counts = h->d_ghist.p;          // zeroed by the kernel: the running histogram of the levels / the counters of MODE_SELF
             hist_live = true;
-            // one block per query: a handful of queries get wide blocks, or a 65 536-row sample is one block's latency-bound walk
-            hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(nq_pad <= 64 ? 1024 : isk::BLOCK), 0, h->stream, bp);
+            if (nq_pad > 64 && h->boot_multi) {
+                // large batches: four queries per 1 024-thread block share every row load of the sample
+                const dim3 bgrid(nq_pad / isk::BOOT_QB), bblock(1024);
+                switch (j.W) {
+                    case 1: hipLaunchKernelGGL(isk::boot_multi_kernel<1>, bgrid, bblock, 0, h->stream, bp); break;
+                    case 2: hipLaunchKernelGGL(isk::boot_multi_kernel<2>, bgrid, bblock, 0, h->stream, bp); break;
+                    case 3: hipLaunchKernelGGL(isk::boot_multi_kernel<3>, bgrid, bblock, 0, h->stream, bp); break;
+                    default: hipLaunchKernelGGL(isk::boot_multi_kernel<4>, bgrid, bblock, 0, h->stream, bp); break;
+                }
+            } else {
+                // one block per query: a handful of queries get wide blocks, or a 65 536-row sample is one block's latency-bound walk
+                hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(nq_pad <= 64 ? 1024 : isk::BLOCK), 0, h->stream, bp);
+            }
 
             if (self) {
                 // 2'. ONE pass over all rows (in cache-sized stretches when several chunks of queries share them):
@@ -986,6 +998,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_tighten")) { h->self_tighten = value != 0; return 0; }
+    if (!strcmp(name, "boot_multi")) { h->boot_multi = value != 0; return 0; }
     if (!strcmp(name, "self_refresh_steps")) {
         if (value < 1 || value > 64 || (value & (value - 1))) return fail(-EINVAL, "self_refresh_steps must be a power of two in 1..64");
         h->self_refresh_steps = (uint32_t)value; return 0;

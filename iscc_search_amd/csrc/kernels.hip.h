@@ -595,6 +595,96 @@ __global__ __launch_bounds__(1024) void boot_kernel(const BootParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// boot_multi_kernel<W>: the same bootstrap for LARGE batches, BOOT_QB queries per 1 024-thread block.  With one block per query
+// 1 024 blocks each read the whole 512 KB sample from the L2 (~0.5 GB per launch, ~11 TB/s for 45 us): here a row is loaded
+// once per BOOT_QB queries and the kernel is bound by its XOR + popcount work instead.  nq_pad is a multiple of 8, hence of 4.
+// ---------------------------------------------------------------------------------------------
+constexpr int BOOT_QB = 4;
+template <int W>
+__global__ __launch_bounds__(1024) void boot_multi_kernel(const BootParams p) {
+    __shared__ uint32_t hist[BOOT_QB][320];
+    __shared__ uint32_t res[2];
+    const uint32_t q0 = blockIdx.x * BOOT_QB, tid = threadIdx.x, nthr = blockDim.x;
+    if (tid < BOOT_QB) p.cnt[(uint64_t)(q0 + tid) * CNT_STRIDE] = 0;
+    if (p.counts)
+        for (uint32_t i = tid; i < BOOT_QB * HB; i += nthr) p.counts[(uint64_t)q0 * HB + i] = 0;
+    for (uint32_t i = tid; i < BOOT_QB * 320; i += nthr) (&hist[0][0])[i] = 0;
+    uint64_t qw[BOOT_QB][W];
+#pragma unroll
+    for (int i = 0; i < BOOT_QB; ++i)
+#pragma unroll
+        for (int w = 0; w < W; ++w) qw[i][w] = p.queries[(uint64_t)(q0 + i) * 4 + w];     // uniform addresses: scalar loads
+    __syncthreads();
+    auto hamming = [&](const uint64_t (&x)[W], int i) {
+        uint32_t h = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint64_t y = x[w] ^ qw[i][w];
+            if (w == W - 1) y &= p.mask_last;
+            h += (uint32_t)__builtin_popcountll(y);
+        }
+        return h;
+    };
+    // (a large k keeps the whole sample exact: the cut of the first rows must leave >= k rows under it)
+    const uint64_t s1 = (p.s0 <= BOOT_EXACT_ROWS || (uint64_t)p.k * 4 > BOOT_EXACT_ROWS) ? p.s0 : BOOT_EXACT_ROWS;
+    for (uint64_t r = tid; r < s1; r += nthr) {
+        uint64_t x[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) x[w] = p.col[w][r];
+#pragma unroll
+        for (int i = 0; i < BOOT_QB; ++i) atomicAdd(&hist[i][hamming(x, i)], 1u);
+    }
+    __syncthreads();
+    uint32_t cut[BOOT_QB], less;
+#pragma unroll
+    for (int i = 0; i < BOOT_QB; ++i) block_find_cut(hist[i], NBINS, p.k < s1 ? p.k : (uint32_t)s1, res, cut[i], less);
+    if (p.s0 > s1) {
+        // bins <= cut[i] become exact over [0, s0); the k-th smallest of query i lies there.  Eight independent rows per
+        // thread and trip, each scored against the block's queries.
+        for (uint64_t r0 = s1 + tid; r0 < p.s0; r0 += 8 * (uint64_t)nthr) {
+            uint64_t x[8][W];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint64_t r = r0 + (uint64_t)u * nthr;
+                const uint64_t rr = r < p.s0 ? r : s1;          // clamped: the value is discarded below
+#pragma unroll
+                for (int w = 0; w < W; ++w) x[u][w] = p.col[w][rr];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool real = r0 + (uint64_t)u * nthr < p.s0;
+#pragma unroll
+                for (int i = 0; i < BOOT_QB; ++i) {
+                    const uint32_t h = hamming(x[u], i);
+                    if (h <= cut[i] && real) atomicAdd(&hist[i][h], 1u);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BOOT_QB; ++i) block_find_cut(hist[i], NBINS, p.k < p.s0 ? p.k : (uint32_t)p.s0, res, cut[i], less);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < BOOT_QB; ++i) {
+            const uint32_t q = q0 + i;
+            if (q >= p.nq) {
+                p.bias[q] = BIAS_NEVER;
+                if (p.thr) p.thr[q] = -1.0e9f;       // below every dot product: never a candidate
+                continue;
+            }
+            p.bias[q] = 0x7FFFFFFFu - cut[i];
+            if (p.thr) {
+                uint32_t pc = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) pc += (uint32_t)__builtin_popcountll(w == W - 1 ? qw[i][w] & p.mask_last : qw[i][w]);
+                p.thr[q] = (float)((int)cut[i] - (int)pc);
+            }
+        }
+    }
+}
+
 struct PickParams {
     const uint32_t* ghist;   // [nq_pad][HB]
     uint32_t* bias;          // [nq_pad] in/out
