@@ -15,7 +15,7 @@ def main():
     with open(path) as f:
         rows = list(csv.DictReader(f))
     seq = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"]) for r in rows))
-    starts = [i for i, s in enumerate(seq) if "boot_kernel" in s[2] or "radius_init_kernel" in s[2]]
+    starts = [i for i, s in enumerate(seq) if "boot_kernel" in s[2] or "boot_multi_kernel" in s[2] or "radius_init_kernel" in s[2]]
     if len(starts) < back + 1:
         raise SystemExit("not enough steps in the trace")
     a, b = starts[-back - 1], starts[-back]
