@@ -98,6 +98,7 @@ typedef struct isccsearch_stats {
     /* batches whose single self-tightening pass (k <= 512 on the matrix cores) overflowed a candidate list and were answered
        again with threshold levels, which prune after every level, before any query took the per-query exact fallback */
     uint64_t self_retries;
+    uint64_t mfma_pack_launches; /* how many of mfma_launches ran the packed form (64-bit codes: two row tiles per accumulator) */
 } isccsearch_stats;
 
 /* Engine lifetime.  One handle drives one GPU (one process per GPU). */
@@ -109,7 +110,9 @@ const char* isccsearch_last_error(void);
  * scanned on the matrix cores -- bits as FP4 0/+-1, exact f32 sums, csrc/mfma_scan.hip -- instead of XOR + popcount;
  * "self_tighten" (0|1, default 1): for k <= "self_max_k" (512) that scan is ONE pass whose thresholds tighten themselves,
  * bootstrapped from "self_boot_rows" (65 536) rows and looking at the live thresholds every "self_refresh_steps" (1) steps,
- * instead of threshold levels growing by "mfma_level_growth" (4)); "candidate_cap" (16 384: floor of the per-query candidate
+ * instead of threshold levels growing by "mfma_level_growth" (4)); "mfma_pack" (0|1, default 1: 64-bit codes run the packed
+ * form of that kernel -- two row tiles per accumulator, v_pk_minimum3_f16 fold -- unless the batch holds an all-zero query);
+ * "candidate_cap" (16 384: floor of the per-query candidate
  * buffer, in entries); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
  * (0|1: time every collect-scan launch with HIP events, read back through isccsearch_stats_get), "stretch_mb" (XOR + popcount
  * kernel: rows per collect launch, in MB of codes, when several query groups share a launch: they then read the stretch from the

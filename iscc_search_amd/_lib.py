@@ -60,6 +60,7 @@ class Stats(ctypes.Structure):
         ("level_mfma_launches", ctypes.c_uint64),
         ("level_ms", ctypes.c_double),
         ("self_retries", ctypes.c_uint64),
+        ("mfma_pack_launches", ctypes.c_uint64),
     ]
 
     def as_dict(self):

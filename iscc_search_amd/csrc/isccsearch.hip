@@ -167,6 +167,7 @@ struct isccsearch_handle {
     bool mfma = true;
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
+    int mfma_pack = 1;                // 64-bit codes on the matrix cores: two row tiles per accumulator, packed f16 fold (mfma_pack_kernel)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
     // k <= self_max_k on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
     // every launch of that chain costs ~35 us of ramp, prologue and tail, and a step of 100 M rows had seven of them
@@ -410,6 +411,7 @@ struct Job {
     uint32_t W;        // words compared
     bool mask;
     uint64_t mask_last;
+    bool pack;         // matrix-core launches run mfma_pack_kernel (one word, no all-zero query in the batch)
 };
 
 struct Batch {
@@ -469,13 +471,14 @@ struct Batch {
         if (use_mfma(rows)) {
             const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad);
             const uint32_t chunks = (nq_pad + g * 32 - 1) / (g * 32);
-            const uint64_t rps = isk::mfma_rows_per_wave_step((int)j.W);
+            const uint64_t rps = isk::mfma_rows_per_wave_step((int)j.W, j.pack);
             const uint64_t steps = (rows + rps - 1) / rps;
             const uint64_t wpb = isk::mfma_waves_per_block();
-            const uint64_t bx = std::max<uint64_t>(1, std::min<uint64_t>((steps + wpb - 1) / wpb, std::max<uint32_t>(1, (uint32_t)h->cus * isk::mfma_blocks_per_cu((int)j.W, g) / chunks)));
-            const int e = isk::launch_mfma_scan((int)j.W, mode, (uint32_t)bx, g, h->stream, sp);
+            const uint64_t bx = std::max<uint64_t>(1, std::min<uint64_t>((steps + wpb - 1) / wpb, std::max<uint32_t>(1, (uint32_t)h->cus * isk::mfma_blocks_per_cu((int)j.W, g, j.pack) / chunks)));
+            const int e = isk::launch_mfma_scan((int)j.W, mode, j.pack, (uint32_t)bx, g, h->stream, sp);
             if (e) return fail(-EIO, "mfma scan: chunk of %u query groups does not fit the LDS budget (%s)", g, hipGetErrorString((hipError_t)e));
             h->stats.mfma_launches += 1;
+            if (j.pack) h->stats.mfma_pack_launches += 1;
             h->stats.mfma_pair_words += rows * (uint64_t)nq * j.W;
             return 0;
         }
@@ -503,6 +506,11 @@ struct Batch {
             j.W = (j.pbytes + 7) / 8;
             j.mask = (j.pbytes & 7) != 0;
             j.mask_last = mask_for(j.pbytes);
+            // the packed fold of mfma_pack_kernel holds a dot product in 7 bits + sign: -64 .. 63.  +64 takes an all-zero query
+            // of 64 compared bits (against a row of all ones): such a batch stays on the unpacked kernel
+            j.pack = h->mfma_pack && j.W == 1;
+            if (j.pack && j.pbytes == 8)
+                for (uint32_t q = 0; q < nq && j.pack; ++q) j.pack = hq[(size_t)q * t.max_words] != 0;
             jobs.push_back(j);
         }
         if (jobs.empty()) {
@@ -1007,6 +1015,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "self_max_k")) { if (value < 1 || value > 512) return fail(-EINVAL, "self_max_k must be 1..512"); h->self_max_k = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
+    if (!strcmp(name, "mfma_pack")) { h->mfma_pack = value != 0; return 0; }
     if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
     return fail(-EINVAL, "unknown option '%s'", name);

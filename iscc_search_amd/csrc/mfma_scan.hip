@@ -364,6 +364,310 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     if constexpr (MODE == MODE_SELF && ASYNC) pend.complete(p, q0, lpop);
 }
 
+
+// =====================================================================================================================
+// mfma_pack_kernel -- 64-bit codes (W = 1): TWO row tiles share ONE accumulator, folded as packed f16
+// =====================================================================================================================
+// The kernel above looks at every (row, query) result once: 15 v_min3_f32 + v_min_f32 + v_cmp per 32 queries x 64 rows,
+// 17 vector instructions beside 64 cycles of matrix-pipe time -- vector ISSUE bound it (pipe 0.485 busy, round 2).  Here the
+// first MFMA of a tile pair adds its dot products (|d| <= 64) to a constant block C = 2^23 + 0x402000 and the second one is
+// the block-SCALED form with scale 2^16 accumulating into the same registers:
+//
+//     bits(acc) = 0x4B402000 + d1 + 65536 * d2        (an f32 in [2^23, 2^24): ulp = 1, every partial sum an exact integer)
+//
+// so the LOW half of every register is 0x2000 + d1 and the HIGH half 0x4B40 + d2: positive, normal f16 bit patterns, whose
+// order as f16 is their order as integers.  v_pk_minimum3_f16 (new in gfx950) folds FOUR results per instruction, and the
+// query's packed threshold T = (first NON-hit pattern of each half) rides in the same fold: "some result <= thr" <=> fold != T.
+// A wave owns FOUR tiles (128 rows, two accumulators): 16 fold instructions + 1 compare + 2 scale loads beside four MFMAs
+// (128 cycles) -- the matrix pipe is the bound again (prototype: tools/proto_pack_scan.hip, profiles/r03_proto_pack_scan.txt).
+//
+// The stage (MFMAs of group g + 1 around the fold of group g) is inline assembly in ISSUE ORDER -- MFMA, four fold
+// instructions, MFMA, ... -- because hipcc moved the builtin MFMAs across the fold and the hit branch whatever
+// sched_barrier said.  hipcc inserts NO hazard nops for assembly, so the distances are kept by construction and counted in
+// INSTRUCTIONS (one wait state each, the rule hipcc itself applies; an 8-pass MFMA result may be read by the VALU 11 wait
+// states after the MFMA): the first eight fold instructions touch accumulator 0 of the old group only (last written by the
+// THIRD MFMA of the previous stage, >= 20 instructions back), accumulator 1 comes after that (>= 20 back as well); a
+// v_pk_minimum3_f16 is never followed directly by a consumer of its result (two interleaved chains; s_nop 0 before the join
+// and the compare); the first and the last group of a step, whose MFMAs / fold stand alone, are padded with s_nop.
+//
+// d2 = +64 (query == 0 against a row of all ones) would carry into the exponent and halve the resolution of the low half:
+// the host routes a batch holding an all-zero 64-bit query to the kernel above (Batch::begin, isccsearch.hip).
+constexpr uint32_t PK_LO0 = 0x2000u, PK_HI0 = 0x4B40u;                 // bit patterns of the two halves at d = 0
+constexpr uint32_t PK_MAGIC = (PK_HI0 << 16) | PK_LO0;                  // 0x4B402000 = 2^23 + 0x402000 as f32
+constexpr int PK_TILES = 4;                                             // row tiles per wave and step
+// hit <=> d <= thr.  The packed threshold holds the first NON-hit pattern of each half; 0 = no row can hit (the fold then
+// returns T itself: +0.0 is the minimum of positive patterns).
+__device__ __forceinline__ uint32_t pack_threshold(float thr) {
+    if (thr < -64.f) return 0u;
+    const uint32_t t1 = (uint32_t)((int)fminf(thr, 64.f) + 1 + 64);     // 0 .. 129
+    return ((PK_HI0 - 64 + t1) << 16) | (PK_LO0 - 64 + t1);
+}
+__device__ __forceinline__ int unpack_threshold(uint32_t tpk) { return (int)(tpk & 0xFFFFu) - (int)PK_LO0 - 1; }
+
+#define ISK_PKM "v_pk_minimum3_f16 "
+#define ISK_MF1(n, av) "v_mfma_f32_32x32x64_f8f6f4 %[" #n "], %[" #av "], %[b], %[mg] cbsz:4 blgp:4\n"
+#define ISK_MF2(n, av) "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #n "], %[" #av "], %[b], %[" #n "], %[sh], %[so] op_sel_hi:[0,0,0] cbsz:4 blgp:4\n"
+
+template <int MODE>
+__global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p, const uint32_t groups) {
+    constexpr int MT = PK_TILES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v4i* lb = reinterpret_cast<v4i*>(smem);
+    uint32_t* lthr = reinterpret_cast<uint32_t*>(smem + (size_t)groups * 64 * 16);      // packed thresholds
+    int* lpop = reinterpret_cast<int*>(lthr + groups * 32);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const uint32_t q0 = blockIdx.y * groups * 32;
+
+    // prologue: as mfma_scan_kernel<1>, thresholds packed
+    for (uint32_t i = tid; i < groups * 32 * 2; i += MBLOCK) {
+        const uint32_t ql = i >> 1, hh = i & 1;
+        const uint32_t q = q0 + ql;
+        const bool live = q < p.nq_pad;
+        const uint64_t qw = live ? p.queries[(uint64_t)q * 4] : 0;
+        const uint32_t x = hh ? (uint32_t)(qw >> 32) : (uint32_t)qw;
+        const uint32_t m = live ? (hh ? p.mask_hi : p.mask_lo) : 0u;
+        const uint32_t g = ql >> 5, c = ql & 31;
+        v4i frag;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) frag[j] = (int)((0x22222222u | (nibbles(x, j) << 3)) & (nibbles(m, j) * 0xFu));
+        lb[(size_t)g * 64 + hh * 32 + c] = frag;
+    }
+    for (uint32_t ql = tid; ql < groups * 32; ql += MBLOCK) {
+        const uint32_t q = q0 + ql;
+        int pc = 0, tau = -1;
+        if (q < p.nq_pad) {
+            pc = __popcll(p.queries[(uint64_t)q * 4] & (((uint64_t)p.mask_hi << 32) | p.mask_lo));
+            tau = (int)(0x7FFFFFFFu - p.bias[q]);
+        }
+        lpop[ql] = pc;
+        if constexpr (MODE == MODE_SELF) lthr[ql] = pack_threshold(q < p.nq_pad ? live_threshold(p.thr_live + q) : -1.0e9f);
+        else lthr[ql] = pack_threshold((float)(tau - pc));
+    }
+    __syncthreads();
+
+    const uint64_t first = p.row_begin / (32 * MT);                         // row_begin is a multiple of the XOR kernel's tile (>= 512 rows)
+    const uint64_t nsteps = (p.n_rows + 32 * MT - 1) / (32 * MT);
+    const uint64_t stride = (uint64_t)gridDim.x * (MBLOCK / 64);
+    // the wave number as a SCALAR: step number and row addresses then live on the scalar unit (scalar-base loads)
+    uint64_t step = first + (uint64_t)blockIdx.x * (MBLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    if (step >= nsteps) return;
+    const uint64_t last_row = p.n_rows - 1;
+    const uint32_t* const col32 = reinterpret_cast<const uint32_t*>(p.col[0]);
+
+    struct Acc { v16f t[2]; };
+    Pending pend;
+    // rare: some lane's fold differs from T.  Half `hf` of register `reg` of accumulator j is row
+    // (2 j + hf) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) of the step; same appends as mfma_scan_kernel.
+    auto hits = [&](const Acc& acc, uint32_t m, uint32_t tpk, uint32_t g, uint64_t st) {
+        if (m != tpk) {
+            // (the step number is uniform and laundered as a scalar, so that hipcc neither hoists 64 row numbers per lane out
+            //  of the group loop nor spends vector registers on it)
+            uint32_t st_lo = (uint32_t)st, st_hi = (uint32_t)(st >> 32);
+            asm volatile("" : "+s"(st_lo), "+s"(st_hi));
+            const uint64_t base = (((uint64_t)st_hi << 32) | st_lo) * (32 * MT) + 4 * h;
+            const uint32_t ql = g * 32 + r;
+            const int pc = lpop[ql];
+            const int thr = unpack_threshold(tpk);
+            int tau_seen = thr + pc;
+            uint32_t nhits = 0, first_off = 0;
+            int first_d = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const uint32_t bits = __float_as_uint(acc.t[j][reg]);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int d = hf ? (int)(bits >> 16) - (int)PK_HI0 : (int)(bits & 0xFFFFu) - (int)PK_LO0;
+                        if (d <= thr) {
+                            const uint32_t off = (uint32_t)((2 * j + hf) * 32 + (reg & 3) + 8 * (reg >> 2));
+                            const uint64_t row = base + off;
+                            if (row <= last_row) {
+                                if constexpr (MODE == MODE_SELF) {
+                                    if (nhits == 0) { first_d = d; first_off = off; }
+                                    else tau_seen = emit_self(p, q0 + ql, d + pc, row, tau_seen, pc);
+                                    nhits += 1;
+                                } else {
+                                    emit<MODE>(p, q0 + ql, (uint32_t)(d + pc), row);
+                                }
+                            }
+                        }
+                    }
+                }
+            if constexpr (MODE == MODE_SELF) {
+                if (nhits) {
+                    pend.complete(p, q0, lpop);
+                    pend.issue(p, q0, ql, first_d + pc, base + first_off, tau_seen);
+                }
+            }
+        }
+    };
+
+    const float mgf = __uint_as_float(PK_MAGIC);
+    v16f magic = {mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf, mgf};
+    asm volatile("" : "+v"(magic));                        // ONE register block for the whole kernel
+    int sc_hi = (int)0x8F8F8F8F, sc_one = 0x7F7F7F7F;      // E8M0 block scales 2^16 and 2^0
+    asm volatile("" : "+v"(sc_hi), "+v"(sc_one));
+    v4i a[MT];
+
+    // stage: MFMAs of the NEW group into `nw`, fold of the OLD group `od` with its packed threshold; returns the lanes whose
+    // fold differs from T as a wave mask and the fold in `m`
+    auto stage = [&](Acc& nw, const Acc& od, const v4i& b, uint32_t tpk, uint32_t& m) -> uint64_t {
+        uint32_t mA, mB;
+        uint64_t mask;
+        const v16f& o0 = od.t[0];
+        const v16f& o1 = od.t[1];
+        asm volatile(ISK_MF1(n0, a0)
+                     ISK_PKM "%[mA], %[t], %[u0], %[u1]\n" ISK_PKM "%[mB], %[u8], %[u9], %[u10]\n"
+                     ISK_PKM "%[mA], %[mA], %[u2], %[u3]\n" ISK_PKM "%[mB], %[mB], %[u11], %[u12]\n"
+                     : [n0] "=&v"(nw.t[0]), [mA] "=&v"(mA), [mB] "=&v"(mB)
+                     : [a0] "v"(a[0]), [b] "v"(b), [mg] "v"(magic), [t] "v"(tpk), [u0] "v"(o0[0]), [u1] "v"(o0[1]), [u2] "v"(o0[2]), [u3] "v"(o0[3]),
+                       [u8] "v"(o0[8]), [u9] "v"(o0[9]), [u10] "v"(o0[10]), [u11] "v"(o0[11]), [u12] "v"(o0[12]));
+        asm volatile(ISK_MF1(n1, a2)
+                     ISK_PKM "%[mA], %[mA], %[u4], %[u5]\n" ISK_PKM "%[mB], %[mB], %[u13], %[u14]\n"
+                     ISK_PKM "%[mA], %[mA], %[u6], %[u7]\n" ISK_PKM "%[mB], %[mB], %[u15], %[w8]\n"
+                     : [n1] "=&v"(nw.t[1]), [mA] "+v"(mA), [mB] "+v"(mB)
+                     : [a2] "v"(a[2]), [b] "v"(b), [mg] "v"(magic), [u4] "v"(o0[4]), [u5] "v"(o0[5]), [u6] "v"(o0[6]), [u7] "v"(o0[7]),
+                       [u13] "v"(o0[13]), [u14] "v"(o0[14]), [u15] "v"(o0[15]), [w8] "v"(o1[8]));
+        asm volatile(ISK_MF2(n0, a1)
+                     ISK_PKM "%[mA], %[mA], %[w0], %[w1]\n" ISK_PKM "%[mB], %[mB], %[w9], %[w10]\n"
+                     ISK_PKM "%[mA], %[mA], %[w2], %[w3]\n" ISK_PKM "%[mB], %[mB], %[w11], %[w12]\n"
+                     : [n0] "+v"(nw.t[0]), [mA] "+v"(mA), [mB] "+v"(mB)
+                     : [a1] "v"(a[1]), [b] "v"(b), [sh] "v"(sc_hi), [so] "v"(sc_one), [w0] "v"(o1[0]), [w1] "v"(o1[1]), [w2] "v"(o1[2]), [w3] "v"(o1[3]),
+                       [w9] "v"(o1[9]), [w10] "v"(o1[10]), [w11] "v"(o1[11]), [w12] "v"(o1[12]));
+        asm volatile(ISK_MF2(n1, a3)
+                     ISK_PKM "%[mA], %[mA], %[w4], %[w5]\n" ISK_PKM "%[mB], %[mB], %[w13], %[w14]\n"
+                     ISK_PKM "%[mA], %[mA], %[w6], %[w7]\n"
+                     "s_nop 0\n"
+                     ISK_PKM "%[mA], %[mA], %[mB], %[w15]\n"
+                     "s_nop 0\n"
+                     "v_cmp_ne_u32_e64 %[mask], %[t], %[mA]\n"
+                     : [n1] "+v"(nw.t[1]), [mA] "+v"(mA), [mB] "+v"(mB), [mask] "=s"(mask)
+                     : [a3] "v"(a[3]), [b] "v"(b), [sh] "v"(sc_hi), [so] "v"(sc_one), [t] "v"(tpk), [w4] "v"(o1[4]), [w5] "v"(o1[5]), [w6] "v"(o1[6]), [w7] "v"(o1[7]),
+                       [w13] "v"(o1[13]), [w14] "v"(o1[14]), [w15] "v"(o1[15]));
+        m = mA;
+        return mask;
+    };
+    // the four MFMAs of a step's FIRST group (nothing to fold beside them), padded so that the first stage may read them
+    auto first_group = [&](Acc& nw, const v4i& b) {
+        asm volatile(ISK_MF1(n0, a0) ISK_MF1(n1, a2) ISK_MF2(n0, a1) ISK_MF2(n1, a3) "s_nop 7\ns_nop 3\n"
+                     : [n0] "=&v"(nw.t[0]), [n1] "=&v"(nw.t[1])
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b] "v"(b), [mg] "v"(magic), [sh] "v"(sc_hi), [so] "v"(sc_one));
+    };
+    // the fold of a step's LAST group: same order as in a stage, no MFMA beside it
+    auto last_fold = [&](const Acc& od, uint32_t tpk, uint32_t& m) -> uint64_t {
+        uint32_t mA, mB;
+        uint64_t mask;
+        const v16f& o0 = od.t[0];
+        const v16f& o1 = od.t[1];
+        asm volatile("s_nop 3\n"
+                     ISK_PKM "%[mA], %[t], %[u0], %[u1]\n" ISK_PKM "%[mB], %[u8], %[u9], %[u10]\n"
+                     ISK_PKM "%[mA], %[mA], %[u2], %[u3]\n" ISK_PKM "%[mB], %[mB], %[u11], %[u12]\n"
+                     ISK_PKM "%[mA], %[mA], %[u4], %[u5]\n" ISK_PKM "%[mB], %[mB], %[u13], %[u14]\n"
+                     ISK_PKM "%[mA], %[mA], %[u6], %[u7]\n"
+                     : [mA] "=&v"(mA), [mB] "=&v"(mB)
+                     : [t] "v"(tpk), [u0] "v"(o0[0]), [u1] "v"(o0[1]), [u2] "v"(o0[2]), [u3] "v"(o0[3]), [u4] "v"(o0[4]), [u5] "v"(o0[5]), [u6] "v"(o0[6]), [u7] "v"(o0[7]),
+                       [u8] "v"(o0[8]), [u9] "v"(o0[9]), [u10] "v"(o0[10]), [u11] "v"(o0[11]), [u12] "v"(o0[12]), [u13] "v"(o0[13]), [u14] "v"(o0[14]));
+        asm volatile(ISK_PKM "%[mB], %[mB], %[u15], %[w8]\n"
+                     ISK_PKM "%[mA], %[mA], %[w0], %[w1]\n" ISK_PKM "%[mB], %[mB], %[w9], %[w10]\n"
+                     ISK_PKM "%[mA], %[mA], %[w2], %[w3]\n" ISK_PKM "%[mB], %[mB], %[w11], %[w12]\n"
+                     ISK_PKM "%[mA], %[mA], %[w4], %[w5]\n" ISK_PKM "%[mB], %[mB], %[w13], %[w14]\n"
+                     ISK_PKM "%[mA], %[mA], %[w6], %[w7]\n"
+                     "s_nop 0\n"
+                     ISK_PKM "%[mA], %[mA], %[mB], %[w15]\n"
+                     "s_nop 0\n"
+                     "v_cmp_ne_u32_e64 %[mask], %[t], %[mA]\n"
+                     : [mA] "+v"(mA), [mB] "+v"(mB), [mask] "=s"(mask)
+                     : [t] "v"(tpk), [u15] "v"(o0[15]), [w0] "v"(o1[0]), [w1] "v"(o1[1]), [w2] "v"(o1[2]), [w3] "v"(o1[3]), [w4] "v"(o1[4]), [w5] "v"(o1[5]), [w6] "v"(o1[6]),
+                       [w7] "v"(o1[7]), [w8] "v"(o1[8]), [w9] "v"(o1[9]), [w10] "v"(o1[10]), [w11] "v"(o1[11]), [w12] "v"(o1[12]), [w13] "v"(o1[13]), [w14] "v"(o1[14]), [w15] "v"(o1[15]));
+        m = mA;
+        return mask;
+    };
+
+    const v4i* const lbl = lb + lane;
+    const uint32_t* const lt = lthr + r;
+    auto row_of = [&](uint64_t st, int t) { const uint64_t row = (st * MT + t) * 32 + r; return row <= last_row ? row : last_row; };
+    // lane (r, h) of tile t reads dword h of row st * 128 + 32 t + r: a uniform base plus a constant per-lane offset; only the
+    // table's last step can be partial and clamps per lane
+    const uint32_t lane_dword = r * 2 + h;
+    auto load_rows = [&](uint64_t st, uint32_t (&dst)[MT]) {
+        if ((st + 1) * (32 * MT) <= p.n_rows) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) dst[t] = (col32 + st * (64 * MT) + t * 64)[lane_dword];
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) dst[t] = col32[row_of(st, t) * 2 + h];
+        }
+    };
+    uint32_t x[MT];
+    load_rows(step, x);
+    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    // thresholds [256 wave, 256 wave + 256) are this wave's to keep fresh, four per lane.  The lane number is RECOMPUTED at
+    // each use (mbcnt of a laundered zero), or hipcc keeps a 64-bit global address and an LDS address alive through the
+    // group loop for two instructions per look -- registers the rare path needs (168 with them: one spilled)
+    auto fresh_index = [&]() {
+        uint32_t z = 0;
+        asm volatile("" : "+v"(z));
+        return wave_s * 256 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) * 4;
+    };
+    const bool refresh = MODE == MODE_SELF && wave * 256 + lane * 4 < groups * 32 && q0 + wave * 256 + lane * 4 < p.nq_pad;
+    // a step is 128 rows here (64 in mfma_scan_kernel): look half as many steps apart for the same rows per look
+    const uint32_t refresh_mask = (groups >= 32 ? 1u : groups >= 16 ? 2u : groups >= 8 ? 4u : groups >= 4 ? 8u : 16u) * ((p.refresh_steps + 1) / 2) - 1u;
+    uint32_t trip = 0;
+    for (; step < nsteps; step += stride, ++trip) {
+        const uint64_t ns = step + stride < nsteps ? step + stride : step;
+        float fresh[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool look = trip < 4 || (trip & refresh_mask) == 0;
+        const bool refresh_now = refresh && look;
+        if constexpr (MODE == MODE_SELF) {
+            if (refresh_now) {
+                const float* const src = p.thr_live + q0 + fresh_index();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fresh[i] = live_threshold(src + i);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            a[t] = v4i{(int)(nibbles(x[t], 0) << 1), (int)(nibbles(x[t], 1) << 1), (int)(nibbles(x[t], 2) << 1), (int)(nibbles(x[t], 3) << 1)};
+        load_rows(ns, x);                                 // the next step's rows, in flight during this one (same registers)
+
+        // two B buffers and two accumulator sets: the fragment of group g + 2 is requested while group g + 1 multiplies
+        v4i by = lbl[0], bx = lbl[64];
+        uint32_t thrY = lt[0], thrX = lt[32];
+        Acc accY, accX;
+        uint32_t mY, mX;
+        first_group(accY, by);
+#pragma unroll 1
+        for (uint32_t g = 0; g + 2 < groups; g += 2) {
+            by = lbl[(g + 2) * 64];                       // consumed by the stage before
+            const uint32_t thrYn = lt[(g + 2) * 32];
+            if (__builtin_expect(stage(accX, accY, bx, thrY, mY) != 0, 0)) hits(accY, mY, thrY, g, step);
+            thrY = thrYn;
+            bx = lbl[(g + 3) * 64];
+            const uint32_t thrXn = lt[(g + 3) * 32];
+            if (__builtin_expect(stage(accY, accX, by, thrX, mX) != 0, 0)) hits(accX, mX, thrX, g + 1, step);
+            thrX = thrXn;
+        }
+        if (stage(accX, accY, bx, thrY, mY) != 0) hits(accY, mY, thrY, groups - 2, step);
+        if (last_fold(accX, thrX, mX) != 0) hits(accX, mX, thrX, groups - 1, step);
+        if constexpr (MODE == MODE_SELF) {
+            if (refresh_now) *reinterpret_cast<uint4*>(lthr + fresh_index()) = make_uint4(pack_threshold(fresh[0]), pack_threshold(fresh[1]), pack_threshold(fresh[2]), pack_threshold(fresh[3]));
+            if (look) pend.complete(p, q0, lpop);
+        }
+    }
+    if constexpr (MODE == MODE_SELF) pend.complete(p, q0, lpop);
+}
+
+static int launch_pack(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
+    if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
+    if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_pack_kernel<MODE_COLLECT>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_pack_kernel<MODE_STRETCH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_SELF) hipLaunchKernelGGL((mfma_pack_kernel<MODE_SELF>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else hipLaunchKernelGGL((mfma_pack_kernel<MODE_BOTH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    return 0;
+}
+
 template <int W>
 static int launch_w(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
     // a chunk's LDS image is <= 40 KB: inside the default dynamic-LDS limit, no per-device function attribute to set
@@ -387,18 +691,19 @@ uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad) {
 size_t mfma_lds_bytes(int W, uint32_t groups) { return (size_t)groups * W * 64 * 16 + (size_t)groups * 32 * 8; }
 
 uint32_t mfma_waves_per_block() { return MBLOCK / 64; }
-uint32_t mfma_rows_per_wave_step(int W) { return 32u * (uint32_t)(W == 4 ? mfma_tiles<4>() : 2); }
+uint32_t mfma_rows_per_wave_step(int W, bool pack) { return pack ? 32u * PK_TILES : 32u * (uint32_t)(W == 4 ? mfma_tiles<4>() : 2); }
 
-uint32_t mfma_blocks_per_cu(int W, uint32_t groups) {
+uint32_t mfma_blocks_per_cu(int W, uint32_t groups, bool pack) {
     const uint32_t by_lds = (uint32_t)((160u * 1024u) / mfma_lds_bytes(W, groups));
-    const uint32_t by_regs = W <= 3 ? 3u : (mfma_tiles<4>() == 1 ? 4u : 2u);
+    const uint32_t by_regs = pack || W <= 3 ? 3u : (mfma_tiles<4>() == 1 ? 4u : 2u);
     return by_lds < by_regs ? (by_lds ? by_lds : 1u) : by_regs;
 }
 
-int launch_mfma_scan(int W, int mode, uint32_t blocks_x, uint32_t groups, hipStream_t st, const ScanParams& p) {
+int launch_mfma_scan(int W, int mode, bool pack, uint32_t blocks_x, uint32_t groups, hipStream_t st, const ScanParams& p) {
     const uint32_t chunks = (p.nq_pad + groups * 32 - 1) / (groups * 32);
     const dim3 grid(blocks_x, chunks);
     const size_t lds = mfma_lds_bytes(W, groups);
+    if (pack) return W == 1 ? launch_pack(mode, grid, lds, st, p, groups) : (int)hipErrorInvalidValue;
     switch (W) {
         case 1: return launch_w<1>(mode, grid, lds, st, p, groups);
         case 2: return launch_w<2>(mode, grid, lds, st, p, groups);

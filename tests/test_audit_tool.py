@@ -144,3 +144,75 @@ def test_still_rejects_a_touch_in_the_merged_exit_block(tmp_path):
     # on the `break` path the loop-head group is in flight until .LBB0_9: reading v7 in the shared exit block is a real hazard
     rc, out = run_merged(tmp_path, in_exit_block="v_mov_b32_e32 v30, v7")
     assert rc == 1 and "touches a destination of the load group" in out, out
+
+
+# ---- the packed matrix-core kernel: distances from an MFMA to the users of its result (invariants 4 and 5) -----------------
+
+PACK_RES = RES + """remark: Function Name: _ZN3isk16mfma_pack_kernelILi0EEEvNS_10ScanParamsEj
+remark:     TotalSGPRs: 60
+remark:     VGPRs: 150
+remark:     AGPRs: 0
+remark:     ScratchSize [bytes/lane]: 0
+remark:     Occupancy [waves/SIMD]: 3
+remark:     SGPRs Spill: 0
+remark:     VGPRs Spill: 0
+"""
+
+PACK_ASM = """_ZN3isk16mfma_pack_kernelILi0EEEvNS_10ScanParamsEj:
+	v_mov_b32_e32 v100, 0
+.LBB1_1:
+	;;#ASMSTART
+	v_mfma_f32_32x32x64_f8f6f4 v[18:33], v[90:93], v[98:101], v[2:17] cbsz:4 blgp:4
+	v_pk_minimum3_f16 v130, v131, v50, v51
+	v_pk_minimum3_f16 v132, v58, v59, v60
+	{second}
+	v_mfma_scale_f32_32x32x64_f8f6f4 v[18:33], v[82:85], v[98:101], v[18:33], v145, v146 op_sel_hi:[0,0,0] cbsz:4 blgp:4
+	;;#ASMEND
+	{pad}
+	s_cmp_lt_u32 s8, s9
+	s_cbranch_scc1 .LBB1_2
+	v_add_u32_e32 v140, 1, v140
+.LBB1_2:
+	{reader}
+	s_cmp_lt_u32 s10, s11
+	s_cbranch_scc1 .LBB1_1
+	s_endpgm
+.Lfunc_end1:
+"""
+
+
+def run_pack(tmp_path, second="v_pk_minimum3_f16 v130, v130, v52, v53", pad="s_nop 7\n\ts_nop 3", reader="v_mov_b32_e32 v141, v18"):
+    a, r = tmp_path / "k.s", tmp_path / "k.res"
+    a.write_text(ASM.format(nop="s_nop 4", extra="s_nop 0") + PACK_ASM.format(second=second, pad=pad, reader=reader))
+    r.write_text(PACK_RES.format(scratch=0, spill=0))
+    p = subprocess.run([sys.executable, TOOL, str(a), str(r)], capture_output=True, text=True)
+    return p.returncode, p.stdout
+
+
+def test_accepts_results_read_far_enough_from_their_mfma(tmp_path):
+    rc, out = run_pack(tmp_path)
+    assert rc == 0 and "2 MFMAs in 1 packed matrix-core kernels" in out, out
+
+
+def test_rejects_a_result_read_too_early_on_any_path(tmp_path):
+    rc, out = run_pack(tmp_path, pad="s_nop 3")                       # 4 + 2 (+ 1 on the longer path) wait states: too few on both
+    assert rc == 1 and "wait states after the MFMA that writes it" in out, out
+    # the SHORT path (branch taken) decides: s_nop 7 + s_nop 0 + s_cmp + s_cbranch = 11 < 12, the fall-through has one more
+    rc, out = run_pack(tmp_path, pad="s_nop 7\n\ts_nop 0")
+    assert rc == 1 and "only 11 wait states" in out, out
+    rc, out = run_pack(tmp_path, pad="s_nop 7\n\ts_nop 1")
+    assert rc == 0, out
+    # a reader of another register is no business of the MFMA
+    rc, out = run_pack(tmp_path, pad="s_nop 7\n\ts_nop 1", reader="v_mov_b32_e32 v141, v50")
+    assert rc == 0, out
+    # ... but with a short pad the next trip's first MFMA overwrites v[18:33] while the scaled one is still in the pipe
+    rc, out = run_pack(tmp_path, pad="s_nop 0", reader="v_mov_b32_e32 v141, v50")
+    assert rc == 1 and "v_mfma_f32_32x32x64_f8f6f4 v[18:33]" in out and "uses v18" in out, out
+    # across the loop's back edge: the first fold instruction of the next trip names v18 (s_cmp + s_cbranch + MFMA in between)
+    rc, out = run_pack(tmp_path, second="v_pk_minimum3_f16 v130, v130, v18, v53", pad="s_nop 7\n\ts_nop 7", reader="s_nop 0")
+    assert rc == 1 and "wait states after the MFMA that writes it" in out, out
+
+
+def test_rejects_a_fold_instruction_that_directly_follows_its_producer(tmp_path):
+    rc, out = run_pack(tmp_path, second="v_pk_minimum3_f16 v132, v132, v52, v53")
+    assert rc == 1 and "follows the v_pk_minimum3_f16 that writes its operand directly" in out, out

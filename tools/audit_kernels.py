@@ -15,6 +15,14 @@ an asm statement (cdna_hip_programming.md section 5.7), so three invariants are 
   3. every such load group opens with ``s_nop 4`` (the scalar bases may come straight from v_readfirstlane / v_readlane: a
      VALU-written SGPR needs 5 wait states before a VMEM instruction reads it).
 
+The packed matrix-core scan (``mfma_pack_kernel`` in csrc/mfma_scan.hip) issues its MFMAs and the fold of their results
+from inline asm in a fixed order; hipcc places no hazard nops for asm, so two more invariants are checked on the assembly:
+
+  4. along EVERY control-flow path, an instruction that reads or writes a VGPR written by a ``v_mfma*`` comes at least
+     MFMA_WAIT_STATES wait states after it (one per instruction, N + 1 for ``s_nop N`` -- the rule hipcc applies to its
+     own code; an accumulating MFMA whose SrcC is its own destination is exempt);
+  5. a ``v_pk_minimum3_f16`` is never followed directly by an instruction that names its destination.
+
 usage: audit_kernels.py <device assembly .s> <kernel-resource-usage remarks .txt>
 """
 import re
@@ -23,7 +31,10 @@ import sys
 KERNEL_RE = re.compile(r"^(_ZN3isk\w+):\s*(;.*)?$")
 LABEL_RE = re.compile(r"^(\.LBB\d+_\d+):")
 VREG_RE = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-AUDITED = ("scan_kernel", "scan_adapt_kernel", "mfma_scan_kernel")
+AUDITED = ("scan_kernel", "scan_adapt_kernel", "mfma_scan_kernel", "mfma_pack_kernel")
+# an 8-pass MFMA (v_mfma_f32_32x32x64_f8f6f4 with FP4 operands) may be read by the VALU 11 wait states after it was issued
+# (LLVM: passes + 3); one more for margin
+MFMA_WAIT_STATES = 12
 
 
 def vregs(text):
@@ -153,6 +164,98 @@ def audit_loads(name, ins):
     return bad, len(groups)
 
 
+def audit_mfma_distances(name, ins):
+    """Invariants 4 and 5 for one kernel; returns (violations, number of MFMAs seen)."""
+    nodes = [(i, t) for i, (t, _) in enumerate(ins) if not t.endswith(":")]
+    index_of = {}                                   # position in `ins` -> node number of the next real instruction
+    nxt = len(nodes)
+    for n in range(len(nodes) - 1, -1, -1):
+        index_of[nodes[n][0]] = n
+    k = len(nodes)
+    for i in range(len(ins) - 1, -1, -1):
+        if i in index_of:
+            k = index_of[i]
+        else:
+            index_of[i] = k
+    labels = {t[:-1]: index_of[i] for i, (t, _) in enumerate(ins) if t.endswith(":")}
+    bad, n_mfma = [], 0
+    succ = []
+    for n, (_, text) in enumerate(nodes):
+        out = []
+        bm = re.match(r"(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", text)
+        if bm:
+            if bm.group(2) in labels:
+                out.append(labels[bm.group(2)])
+            if bm.group(1) != "s_branch" and n + 1 < len(nodes):
+                out.append(n + 1)
+        elif not text.startswith("s_endpgm") and n + 1 < len(nodes):
+            out.append(n + 1)
+        succ.append(out)
+
+    def operands(text):
+        parts = text.split(None, 1)
+        return [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+
+    # forward dataflow: state = {vgpr: wait states since the MFMA that wrote it}, entries dropped once safe; meet = minimum
+    state = [None] * len(nodes)
+    state[0] = {}
+    work = [0]
+    reported = set()
+    while work:
+        n = work.pop()
+        cur = dict(state[n])
+        text = nodes[n][1]
+        op = text.split()[0]
+        if op.startswith("v_mfma"):
+            ops = operands(text)
+            dst = vregs(ops[0])
+            srcc = vregs(ops[3]) if len(ops) > 3 else set()
+            touched = set()
+            for o in ops[1:3] + ops[4:]:
+                touched |= vregs(o.split()[0]) if o else set()
+            if srcc != dst:
+                touched |= srcc
+            hot = sorted(r for r in touched | (dst if srcc != dst else set()) if r in cur)
+            if hot and n not in reported:
+                reported.add(n)
+                bad.append(f"{name}: `{text}` (#{nodes[n][0]}) uses v{hot[0]} {cur[hot[0]]} wait states after the MFMA that writes it")
+            n_mfma += 1 if n not in reported else 0
+            step = 1
+            cur = {r: w + step for r, w in cur.items() if w + step < MFMA_WAIT_STATES}
+            for r in dst:
+                cur[r] = 0
+        else:
+            hot = sorted(r for r in vregs(text) if r in cur) if not op.startswith("s_") else []
+            if hot and n not in reported:
+                reported.add(n)
+                bad.append(f"{name}: `{text}` (#{nodes[n][0]}) touches v{hot[0]} only {cur[hot[0]]} wait states after the MFMA that writes it (need {MFMA_WAIT_STATES})")
+            m = re.match(r"s_nop\s+(\d+)", text)
+            step = int(m.group(1)) + 1 if m else 1
+            cur = {r: w + step for r, w in cur.items() if w + step < MFMA_WAIT_STATES}
+        for t in succ[n]:
+            old = state[t]
+            if old is None:
+                state[t] = dict(cur)
+                work.append(t)
+            else:
+                merged = dict(old)
+                changed = False
+                for r, w in cur.items():
+                    if r not in merged or w < merged[r]:
+                        merged[r] = w
+                        changed = True
+                if changed:
+                    state[t] = merged
+                    work.append(t)
+    n_mfma = sum(1 for _, t in nodes if t.startswith("v_mfma"))
+    for n, (_, text) in enumerate(nodes[:-1]):
+        if text.startswith("v_pk_minimum3_f16"):
+            dst = vregs(operands(text)[0])
+            if dst & vregs(nodes[n + 1][1]) and n + 1 in succ[n]:
+                bad.append(f"{name}: `{nodes[n + 1][1]}` (#{nodes[n + 1][0]}) follows the v_pk_minimum3_f16 that writes its operand directly")
+    return bad, n_mfma
+
+
 def audit_resources(path):
     txt = open(path).read()
     rows, bad = [], []
@@ -185,13 +288,23 @@ def main():
             if n:
                 n_kernels += 1
                 n_groups += n
+    n_pack = n_mfma = 0
+    for name, ins in kernels.items():
+        if "mfma_pack_kernel" in name:
+            b, n = audit_mfma_distances(name, ins)
+            bad += b
+            n_pack += 1
+            n_mfma += n
     if "-v" in sys.argv:
         for r in rows:
             print("%-70s SGPR=%-3d VGPR=%-3d AGPR=%-3d waves/SIMD=%d sgpr_spill=%-3d vgpr_spill=%d scratch=%d" % (
                 r["name"][:70], r["sgpr"], r["vgpr"], r["agpr"], r["occ"], r["sgpr_spill"], r["vgpr_spill"], r["scratch"]))
     spills = [r["sgpr_spill"] for r in rows]
     print(f"audit: {len(rows)} scan kernels, 0 scratch / 0 VGPR spills required; SGPR spills {min(spills) if spills else 0}..{max(spills) if spills else 0} (to VGPR lanes, allowed); "
-          f"{n_groups} asm load groups in {n_kernels} kernels checked against their counted waits")
+          f"{n_groups} asm load groups in {n_kernels} kernels checked against their counted waits; "
+          f"{n_mfma} MFMAs in {n_pack} packed matrix-core kernels checked for {MFMA_WAIT_STATES} wait states to every use of their results")
+    if any("mfma_scan_kernel" in name for name in kernels) and n_pack == 0:
+        bad.append("the matrix-core kernels are in the build but no mfma_pack_kernel was audited: update tools/audit_kernels.py")
     if n_kernels == 0 or not rows:
         bad.append("nothing was audited: kernel names or the asm-load pattern changed; update tools/audit_kernels.py")
     for b in bad[:40]:
