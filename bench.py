@@ -58,7 +58,7 @@ MFMA_FP4_PEAK_TOPS = SIMDS * 4096 * CLOCK_HZ / 1e12     # v_mfma_scale_f32_32x32
 def valu_peak_gtriples(words):
     """(row, query, word) triples per second at full VALU issue: 64 lanes / ((4 + 0.5 / W) instructions x 4 cycles) per SIMD."""
     return SIMDS * CLOCK_HZ * 64 / ((4.0 + 0.5 / words) * 4.0) / 1e9
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_fetch_size.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_fetch_size.json")
 
 
 def splitmix64(x):
@@ -105,7 +105,10 @@ def roofline_of(st, args, words, regime):
     out = {
         "launches": launches,
         "avg_launch_ms": st["scan_ms"] / launches,
-        "algorithmic_bytes_per_launch": st["scan_bytes"] / launches,       # rows x 8 x words x passes of T_q queries
+        # SURVEY 8d's accounting: rows x 8 x words x passes of T_q queries.  The XOR + popcount kernel really streams that;
+        # the matrix-core kernel reads the rows ONCE per chunk of up to 1 024 queries, so there the figure is only what the
+        # same work would have cost in passes of T_q queries (`section8d_bytes_equivalent`), never bytes it moved
+        ("section8d_bytes_equivalent" if mfma else "algorithmic_bytes_per_launch"): st["scan_bytes"] / launches,
         "triples_per_launch": st["scan_pair_words"] / launches,            # (row, query, 64-bit word)
         "scan_ms_per_step": st["scan_ms"] / max(1, st["searches"]),        # device time of the scan launches of one step
         "regime": regime,
@@ -116,10 +119,14 @@ def roofline_of(st, args, words, regime):
         # (the fold: 16 results per lane per 1 024 pairs + the MFMAs' own issue slots) ~90 %; the chip holds ~2.05 GHz.
         # k <= 512: ONE launch per step (MODE_SELF, thresholds tighten themselves); larger k: threshold levels + collect pass.
         single = st["level_launches"] == 0
-        out.update({"bound": "mfma", "kernel": "isk::mfma_scan_kernel<W=%d> (v_mfma_f32_32x32x64_f8f6f4, FP4 operands), %s" % (
-                        words, "one self-tightening pass per step" if single else "levels + collect"),
+        packed = st.get("mfma_pack_launches", 0) > 0
+        out.update({"bound": "mfma", "kernel": "isk::%s (v_mfma_f32_32x32x64_f8f6f4, FP4 operands), %s" % (
+                        "mfma_pack_kernel: two row tiles per accumulator, v_pk_minimum3_f16 fold" if packed else "mfma_scan_kernel<W=%d>" % words,
+                        "one self-tightening pass per step" if single else "levels + collect"),
                     "achieved": ops / secs / 1e12, "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s (FP4, dense)",
-                    "co_limiter": "vector issue: the per-result fold shares the SIMD's issue port with the MFMAs"})
+                    "rows_bytes_per_launch": st["scan_pair_words"] / max(1, st["queries"] // max(1, st["searches"])) * 8 / launches,
+                    "co_limiter": "the chip's clock under matrix load (~1.9 of the 2.4 GHz the peak assumes: profiles/r03_proto_pack_scan.txt)" if packed
+                                  else "vector issue: the per-result fold shares the SIMD's issue port with the MFMAs"})
     elif streaming:
         out.update({"bound": "hbm", "kernel": "isk::scan_adapt_kernel / scan_kernel (XOR + popcount), one pass of T_q queries per table read",
                     "achieved": st["scan_bytes"] / 1e9 / secs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -148,6 +155,8 @@ def attach_traffic(roof, key):
         entry = pmc["regimes"][key]
         roof["traffic"] = entry["corrected_bytes_per_launch"] * roof["triples_per_launch"] / entry["triples_per_launch"]
         roof["traffic_source"] = "%s [%s], kernels at commit %s" % (PMC_PROFILE, key, pmc.get("commit", "?"))
+        # the memory picture of the same launch: HBM bytes / launch time against the 8 TB/s peak
+        roof["hbm_traffic_frac"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
@@ -166,6 +175,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries timed (and parity-checked) on the CPU (0 = auto, ~10-30 s)")
     ap.add_argument("--no-profile", action="store_true", help="do not time scan launches with HIP events")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 3 and 5 after the timed region")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the VALU / HBM-streaming measurements after the timed region")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0 and the process group runs over gloo "
@@ -251,8 +261,8 @@ def main():
             assert int(keys[j, 0]) == r or int(ham[j, 0]) == 0
     assert np.all(np.diff(ham.astype(np.int64), axis=1)[:, : args.k - 1] >= 0), "results not sorted"
 
-    def measure(steps, timed):
-        """`steps` steps with per-launch HIP events; returns (seconds, statistics)."""
+    def measure(steps):
+        """`steps` steps with per-launch HIP events; returns (seconds, statistics).  The LAST step's answer must equal `first`."""
         fence()
         engine.stats(reset=True)
         if not args.no_profile:
@@ -265,10 +275,23 @@ def main():
         el = time.perf_counter() - t0
         engine.set_option("profile", 0)
         st = engine.stats(reset=True)
-        if not timed:
-            for a, b in zip(out, first):
-                assert np.array_equal(a, b), "a regime returned different results"
+        for name, a, b in zip(("keys", "hamming", "prefix_bits", "count"), out, first):
+            if not np.array_equal(a, b):
+                raise SystemExit(f"PARITY FAILURE: the last measured step returned different {name} than the gate step")
         return el, st
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # The UNSETTLED figure first (ADVICE r2 / VERDICT r2): W warm-up steps and K timed steps of a process that has done nothing
+    # but build the index and answer the gate step -- what `--steps K --warmup W` meant before the settle loop existed.
+    for _ in range(args.warmup):
+        step()
+    el_unsettled, _ = measure(args.steps)
+    el_unsettled = max_over_ranks(el_unsettled)
 
     # Clock settle, before the W warm-up steps and outside every timing: a fresh process finds the GPU in its idle power
     # state, and the matrix-core kernel of this step takes ~15 steps (~50 ms) to reach its steady clock (3.46 -> 2.86 ms per
@@ -287,12 +310,8 @@ def main():
                 break
     for _ in range(args.warmup):
         step()
-    elapsed, st = measure(args.steps, True)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, st = measure(args.steps)
+    elapsed = max_over_ranks(elapsed)
 
     batched = args.queries > args.tq
     mfma_on = opts["mfma"] and args.queries >= opts["mfma_min_queries"]
@@ -321,7 +340,7 @@ def main():
             for k_, v_ in o.items():
                 engine.set_option(k_, v_)
             step()
-            el, s2 = measure(5, False)
+            el, s2 = measure(5)
             r2 = roofline_of(s2, args, words, regime_name(False, o["stretch_mb"]))
             if r2:
                 r2["queries_per_s"] = args.queries * 5 / el
@@ -341,6 +360,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "settle_steps": settle_steps,          # untimed, before the warm-up: see the comment at the loop
+        "value_unsettled": total_queries / el_unsettled,   # the first `steps` steps after `warmup` of the fresh process, no settle loop
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
@@ -360,13 +380,12 @@ def main():
             "parallelism": f"row-shard x{world}, one all-gather of per-shard top-k",
         },
         "roofline": roof,
-        # every row is read exactly once per pass: the threshold levels (sample_bytes) stream the first stretch of
-        # the table, the collect scan (scan_bytes) the rest
-        "whole_step_algorithmic_GBs": ((st["scan_bytes"] + st["sample_bytes"]) / 1e9) / elapsed,
         "fallback_queries": st["fallback_queries"],
     }
     out.update(extra)
 
+    if rank == 0 and world == 1 and not args.no_other_configs and not args.no_cpu_baseline and args.nbytes == 8 and not nphd:
+        out["other_configs"] = other_configs(engine, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, q, words, first)
         out["parity_checked_queries"] = out["cpu_baseline"]["parity_checked_queries"]
@@ -417,6 +436,76 @@ def py_memory_style(n_assets=2500, n_queries=200):
     dt = time.perf_counter() - t0
     return {"value": n_queries / dt, "unit": "searches/s", "cores": 1, "kind": "port",
             "sample": f"{n_queries} iscc_code equality searches over {n_assets} assets (config 1: 10 000 units); no distance computed"}
+
+
+def slab_oracle(rows, nbytes, q, k, nphd, key_words, slab=12_500_000):
+    """The oracle over a synthetic table too large for one host array: exact top-k per slab of rows, merged under (distance, key)."""
+    from oracle import oracle_splitmix64_fill, oracle_topk
+
+    words = (nbytes + 7) // 8
+    qn = np.full(len(q), nbytes, dtype=np.uint8) if nphd else None
+    best = [[] for _ in range(len(q))]
+    for lo in range(0, rows, slab):
+        n = min(slab, rows - lo)
+        cw = np.ascontiguousarray(np.stack([oracle_splitmix64_fill(n, SEED_CODES, first=lo, stride=4, lane=w) for w in range(words)], axis=1))
+        rk = np.arange(lo, lo + n, dtype=np.uint64)
+        keys = np.stack([np.zeros(n, dtype=np.uint64), rk], axis=1) if key_words == 2 else rk
+        lens = np.full(n, nbytes, dtype=np.uint8) if nphd else None
+        kk, hh, _, cc = oracle_topk(1 if nphd else 0, keys, cw, lens, q, qn, k, fixed_nbytes=0 if nphd else nbytes)
+        for i in range(len(q)):
+            c = int(cc[i])
+            low = kk[i, :c, 1] if key_words == 2 else kk[i, :c]
+            best[i].extend(zip(hh[i, :c].tolist(), low.tolist()))
+    return [sorted(c)[:k] for c in best]
+
+
+def other_configs(engine, args):
+    """
+    BASELINE configs 3 and 5 in the same process, after the timed region (N = 1): a few steps each with HIP events around the
+    scan launches, four queries checked against the oracle (slab-wise), the last step compared with the first.
+    """
+    from iscc_search_amd import _lib
+
+    out = {}
+    cases = (
+        ("config3", "100 M x 256-bit ISCC-UNITs, NPHD, 1 024 queries, k = 10", dict(rows=100_000_000, nbytes=32, nphd=True, key_words=1, nq=1024, k=10, steps=3)),
+        ("config5_shape", "10 M x 128-bit chunk fingerprints, 128-bit keys, 512 queries, k = 400 (one of config 5's three tables)",
+         dict(rows=10_000_000, nbytes=16, nphd=False, key_words=2, nq=512, k=400, steps=5)),
+    )
+    for name, what, c in cases:
+        words = (c["nbytes"] + 7) // 8
+        t = engine.open_table(_lib.METRIC_NPHD if c["nphd"] else _lib.METRIC_HAMMING, c["key_words"], c["nbytes"])
+        try:
+            t.add_synthetic(c["nbytes"], c["rows"], SEED_CODES)
+            q, planted = make_queries(c["nq"], c["rows"], words)
+            qn = np.full(c["nq"], c["nbytes"], dtype=np.uint8) if c["nphd"] else None
+            first = t.search(q, qn, c["k"])
+            engine.stats(reset=True)
+            engine.set_option("profile", 1)
+            t0 = time.perf_counter()
+            for _ in range(c["steps"]):
+                last = t.search(q, qn, c["k"])
+            el = time.perf_counter() - t0
+            engine.set_option("profile", 0)
+            st = engine.stats(reset=True)
+            for a, b in zip(first, last):
+                if not np.array_equal(a, b):
+                    raise SystemExit(f"PARITY FAILURE ({name}): two steps returned different results")
+            pick = [0, 1, 2, c["nq"] - 1]
+            exp = slab_oracle(c["rows"], c["nbytes"], q[pick], c["k"], c["nphd"], c["key_words"])
+            keys, ham, _, cnt = first
+            for j, e in zip(pick, exp):
+                low = keys[j, :, 1] if c["key_words"] == 2 else keys[j]
+                got = list(zip(ham[j, : int(cnt[j])].tolist(), low[: int(cnt[j])].tolist()))
+                if got != e:
+                    raise SystemExit(f"PARITY FAILURE ({name}): query {j} differs from the oracle")
+            roof = roofline_of(st, args, words, "matrix cores")
+            out[name] = {"workload": what, "queries_per_s": c["nq"] * c["steps"] / el, "ms_per_step": el / c["steps"] * 1e3, "steps": c["steps"],
+                         "parity_checked_queries": len(pick), "fallback_queries": st["fallback_queries"],
+                         "roofline": None if roof is None else {k_: roof[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}}
+        finally:
+            t.drop()
+    return out
 
 
 def cpu_baseline(args, q, words, gpu):

@@ -468,7 +468,9 @@ struct Batch {
     bool use_mfma(uint64_t rows) const { return h->mfma && nq_pad >= h->mfma_min_queries && rows >= h->mfma_min_rows; }
     int scan(const Job& j, const isk::ScanParams& sp, int mode, bool sample) {
         const uint64_t rows = sp.n_rows - sp.row_begin;
-        if (use_mfma(rows)) {
+        // A self-tightening pass is decided once per job (use_mfma over the whole segment) and lives on the matrix cores: EVERY
+        // stretch of it runs there, also a short last one -- the XOR + popcount kernels have no MODE_SELF
+        if (use_mfma(rows) || mode == isk::MODE_SELF) {
             const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad);
             const uint32_t chunks = (nq_pad + g * 32 - 1) / (g * 32);
             const uint64_t rps = isk::mfma_rows_per_wave_step((int)j.W, j.pack);
@@ -482,6 +484,7 @@ struct Batch {
             h->stats.mfma_pair_words += rows * (uint64_t)nq * j.W;
             return 0;
         }
+        if (mode != isk::MODE_COLLECT && mode != isk::MODE_STRETCH && mode != isk::MODE_BOTH) return fail(-EINVAL, "scan mode %d has no XOR + popcount kernel", mode);
         if (sp.n_rows / (uint64_t)tile_rows_for((int)j.W) >= (1ull << 31)) return fail(-E2BIG, "segment of %llu rows exceeds the scan kernel's 2^31 tiles", (unsigned long long)sp.n_rows);
         launch_scan((int)j.W, j.mask, tq, mode, h->nontemporal, dim3(scan_grid_x(h, j.W, rows, groups, sample), groups), h->stream, sp);
         return 0;
@@ -602,7 +605,7 @@ struct Batch {
                     h->stats.scan_passes += groups;
                     h->stats.scan_bytes += rows * 8 * j.W * groups;
                     h->stats.scan_pair_words += rows * (uint64_t)nq * j.W;
-                    if (use_mfma(rows)) h->stats.scan_mfma_launches += 1;
+                    if (use_mfma(rows) || self) h->stats.scan_mfma_launches += 1;
                     a = b;
                 }
                 return 0;
@@ -631,6 +634,7 @@ struct Batch {
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
             bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.cnt = h->d_cnt.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
             bp.thr = self ? h->d_thr.p : nullptr;
+            bp.thr_packed = j.pack ? 1u : 0u;          // mfma_pack_kernel keeps (and lowers) its live thresholds packed
             bp.counts = h->d_ghist.p;          // zeroed by the kernel: the running histogram of the levels / the counters of MODE_SELF
             hist_live = true;
             if (nq_pad > 64 && h->boot_multi) {

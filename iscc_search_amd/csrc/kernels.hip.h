@@ -505,8 +505,14 @@ struct BootParams {
     uint32_t W;
     uint64_t mask_last;
     float* thr;               // [nq_pad] out, nullable: tau0 - popc(query) as the MFMA scan compares it (MODE_SELF)
+    uint32_t thr_packed;      // ... written PACKED (pack_threshold, scan_params.hip.h) for mfma_pack_kernel
     uint32_t* counts;         // [nq_pad][HB], nullable: zeroed here -- the distance counters of the self-tightening pass
 };
+// the bootstrap threshold (dot-product form: tau0 - popc(query); never = no row can be a candidate) in the scan's representation
+__device__ __forceinline__ void store_boot_threshold(const BootParams& p, uint32_t q, int thr, bool never) {
+    if (p.thr_packed) reinterpret_cast<uint32_t*>(p.thr)[q] = never ? 0u : pack_threshold(thr);
+    else p.thr[q] = never ? -1.0e9f : (float)thr;
+}
 constexpr uint64_t BOOT_EXACT_ROWS = 4096;   // rows of the full histogram; the rest of a longer sample only counts under its cut
 
 // the longer part of the bootstrap sample: rows [s1, s0) that lie at or under `cut` go into the histogram.  W is a
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(1024) void boot_kernel(const BootParams p) {
     if (q >= p.nq) {
         if (tid == 0) {
             p.bias[q] = BIAS_NEVER;
-            if (p.thr) p.thr[q] = -1.0e9f;       // below every dot product: never a candidate
+            if (p.thr) store_boot_threshold(p, q, 0, true);       // below every dot product: never a candidate
         }
         return;
     }
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(1024) void boot_kernel(const BootParams p) {
         if (p.thr) {
             uint32_t pc = 0;
             for (uint32_t w = 0; w < p.W; ++w) pc += (uint32_t)__builtin_popcountll(w == p.W - 1 ? qw[w] & p.mask_last : qw[w]);
-            p.thr[q] = (float)((int)bin - (int)pc);
+            store_boot_threshold(p, q, (int)bin - (int)pc, false);
         }
     }
 }
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(1024) void boot_multi_kernel(const BootParams p) {
             const uint32_t q = q0 + i;
             if (q >= p.nq) {
                 p.bias[q] = BIAS_NEVER;
-                if (p.thr) p.thr[q] = -1.0e9f;       // below every dot product: never a candidate
+                if (p.thr) store_boot_threshold(p, q, 0, true);       // below every dot product: never a candidate
                 continue;
             }
             p.bias[q] = 0x7FFFFFFFu - cut[i];
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(1024) void boot_multi_kernel(const BootParams p) {
                 uint32_t pc = 0;
 #pragma unroll
                 for (int w = 0; w < W; ++w) pc += (uint32_t)__builtin_popcountll(w == W - 1 ? qw[i][w] & p.mask_last : qw[i][w]);
-                p.thr[q] = (float)((int)cut[i] - (int)pc);
+                store_boot_threshold(p, q, (int)cut[i] - (int)pc, false);
             }
         }
     }

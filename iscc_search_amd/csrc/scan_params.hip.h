@@ -39,8 +39,22 @@ struct ScanParams {
     uint32_t fold_tau;          // scan_adapt_kernel: groups whose thresholds are all <= this take the folded fast path (0: never)
     uint32_t nq_pad;            // queries (bias entries) behind `queries` / `bias`: the MFMA kernel pads its last chunk itself
     float* thr_live;            // [nq_pad] MODE_SELF: live threshold of every query as the MFMA kernel compares it: tau - popc(query)
+                                //          (mfma_pack_kernel: the same number PACKED, see pack_threshold; boot kernels write either form)
     uint32_t refresh_steps;     // MODE_SELF: a wave re-reads its share of the live thresholds every this many steps of a full chunk (power of two)
 };
+
+// mfma_pack_kernel (mfma_scan.hip) keeps two dot products per f32 accumulator: bits = 0x4B402000 + d1 + 65536 * d2, i.e. the
+// LOW half is PK_LO0 + d1 and the HIGH half PK_HI0 + d2, both positive normal f16 patterns.  A threshold (hit <=> d <= thr)
+// travels as the first NON-hit pattern of each half in one word; 0 = no row can hit.  Monotone in thr, so the live
+// thresholds of the self-tightening pass are lowered with ONE atomicMin on the packed word.
+constexpr uint32_t PK_LO0 = 0x2000u, PK_HI0 = 0x4B40u;                 // bit patterns of the two halves at d = 0
+constexpr uint32_t PK_MAGIC = (PK_HI0 << 16) | PK_LO0;                  // 0x4B402000 = 2^23 + 0x402000 as f32
+__host__ __device__ __forceinline__ uint32_t pack_threshold(int thr) {
+    if (thr < -64) return 0u;
+    const uint32_t t1 = (uint32_t)((thr > 64 ? 64 : thr) + 1 + 64);     // 0 .. 129
+    return ((PK_HI0 - 64 + t1) << 16) | (PK_LO0 - 64 + t1);
+}
+__host__ __device__ __forceinline__ int unpack_threshold(uint32_t tpk) { return (int)(tpk & 0xFFFFu) - (int)PK_LO0 - 1; }
 
 // returns the candidate's slot in the query's list (0 in MODE_HIST)
 template <int MODE>
@@ -68,7 +82,15 @@ __device__ __forceinline__ void lower_threshold(float* addr, float v) {
     }
 }
 
+// the live threshold of query qi := min(itself, thr), in the representation the running kernel keeps (PACKED: mfma_pack_kernel)
+template <bool PACKED>
+__device__ __forceinline__ void lower_live(const ScanParams& p, uint32_t qi, int thr) {
+    if constexpr (PACKED) atomicMin(reinterpret_cast<uint32_t*>(p.thr_live) + qi, pack_threshold(thr));
+    else lower_threshold(p.thr_live + qi, (float)thr);
+}
+
 // returns the (possibly lowered) threshold this lane goes on with
+template <bool PACKED = false>
 __device__ __forceinline__ int emit_self(const ScanParams& p, uint32_t qi, int h, uint64_t row, int tau_seen, int popc_q) {
     // both atomics are in flight together: one round trip to the L2 per candidate (the common case has h == tau_seen or
     // tau_seen - 1, i.e. none or one counter to bump)
@@ -80,7 +102,7 @@ __device__ __forceinline__ int emit_self(const ScanParams& p, uint32_t qi, int h
     if (!counted) return tau_seen;
     for (int t = h;;) {
         if (before + 1 >= p.k) {
-            lower_threshold(p.thr_live + qi, (float)(t - popc_q));
+            lower_live<PACKED>(p, qi, t - popc_q);
             return t;
         }
         if (++t >= tau_seen) return tau_seen;
