@@ -422,7 +422,9 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     for (uint32_t i = tid; i < groups * 32 * 2; i += MBLOCK) {
         const uint32_t ql = i >> 1, hh = i & 1;
         const uint32_t q = q0 + ql;
-        const bool live = q < p.nq_pad;
+        // padding queries (bias BIAS_NEVER: beyond the batch's real queries) are all-zero words: as live queries they would score
+        // +64 against a row of all ones, the one value the packed high half cannot hold -- their fragment is ZERO (every dot 0)
+        const bool live = q < p.nq_pad && p.bias[q] != BIAS_NEVER;
         const uint64_t qw = live ? p.queries[(uint64_t)q * 4] : 0;
         const uint32_t x = hh ? (uint32_t)(qw >> 32) : (uint32_t)qw;
         const uint32_t m = live ? (hh ? p.mask_hi : p.mask_lo) : 0u;
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                             for (int hf = 0; hf < 2; ++hf) {
                                 if (hf ? u[i] < thi : (u[i] & 0xFFFFu) < tlo) {
                                     const int d = hf ? (int)(u[i] >> 16) - (int)PK_HI0 : (int)(u[i] & 0xFFFFu) - (int)PK_LO0;
+                                    if (d < -64) continue;      // not a dot product of 64 bits: never index anything with it
                                     const uint32_t off = (uint32_t)((2 * j + hf) * 32 + (reg & 3) + 8 * (reg >> 2));
                                     const uint64_t row = base + off;
                                     if (row <= last_row) {
