@@ -394,6 +394,7 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 // d2 = +64 (query == 0 against a row of all ones) would carry into the exponent and halve the resolution of the low half:
 // the host routes a batch holding an all-zero 64-bit query to the kernel above (Batch::begin, isccsearch.hip).
 constexpr int PK_TILES = 4;                                             // row tiles per wave and step
+constexpr uint32_t PK_RING_ENTRIES = 8, PK_RING_ENTRY_DWORDS = 36;      // per wave: saved accumulator blocks of lanes that hold a hit (144 B each)
 __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const h2 x = __builtin_bit_cast(h2, a), y = __builtin_bit_cast(h2, b), z = __builtin_bit_cast(h2, c);
@@ -457,66 +458,63 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     const uint32_t* const col32 = reinterpret_cast<const uint32_t*>(p.col[0]);
 
     struct Acc { v16f t[2]; };
+    // ---- candidates ------------------------------------------------------------------------------------------------------------
+    // A stage whose fold differs from T in some lane costs the hot loop NO global memory operation and no unrolled search: the
+    // lanes that hold a hit copy their 32 accumulator registers (+ query, threshold) into their wave's LDS ring -- slots from
+    // the compare's own lane mask, so the count stays wave-uniform -- and the stage loop goes on.  At the end of the step (or
+    // when the ring is full) `process_ring` walks the saved blocks with a REAL loop: lane v looks at result v of a block (64
+    // results: 32 registers x 2 halves), so the search for the hit is one compare per lane instead of 64 unrolled compares
+    // with a branch each, and every hit of a block is appended by its own lane with all atomics in flight together.  Their
+    // results are consumed by `Pending` at the lane's next hit or at the end of the NEXT step, when they (and the row prefetch,
+    // which shares the in-order vmcnt) have long arrived.  Before: the 64 compares and two returned atomics per candidate sat in
+    // the stage loop behind a vmcnt(0) that also waited for the row prefetch -- ~1.9 us of wave time per candidate (k = 100:
+    // 3.5 ms per 100 M x 1 024 pass against 2.3 for k = 1, profiles/r03_ab_self.txt).
+    constexpr uint32_t RING_E = PK_RING_ENTRIES, ENTRY = PK_RING_ENTRY_DWORDS;       // dwords: 32 registers | query, lane half | T | pad
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(lpop + groups * 32) + wave * (RING_E * ENTRY);
+    uint32_t rcount = 0;                        // saved blocks in the ring (wave-uniform)
     Pending pend;
-    // rare: some lane's fold differs from T.  Half `hf` of register `reg` of accumulator j is row
-    // (2 j + hf) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) of the step; same appends as mfma_scan_kernel.
-    auto hits = [&](const Acc& acc, uint32_t m, uint32_t tpk, uint32_t g, uint64_t st) {
-        if (m != tpk) {
-            // (the step number is uniform and laundered as a scalar, so that hipcc neither hoists 64 row numbers per lane out
-            //  of the group loop nor spends vector registers on it)
-            uint32_t st_lo = (uint32_t)st, st_hi = (uint32_t)(st >> 32);
-            asm volatile("" : "+s"(st_lo), "+s"(st_hi));
-            const uint64_t base = (((uint64_t)st_hi << 32) | st_lo) * (32 * MT) + 4 * h;
-            const uint32_t ql = g * 32 + r;
-            const int pc = lpop[ql];
-            const int thr = unpack_threshold(tpk);
-            int tau_seen = thr + pc;
-            uint32_t nhits = 0, first_off = 0;
-            int first_d = 0;
-            const uint32_t tlo = tpk & 0xFFFFu, thi = tpk & 0xFFFF0000u;
-            // a lane nearly always holds ONE hit among its 64 results: fold each quarter (8 registers) once more and look only
-            // into quarters that hold one -- 4 x 5 instructions instead of 64 compares with a branch each (a candidate cost
-            // ~1.7 us of wave time before: k = 100 scanned at 3.67 ms against 2.42 for k = 1)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int qd = 0; qd < 2; ++qd) {
-                    uint32_t u[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) u[i] = __float_as_uint(acc.t[j][8 * qd + i]);
-                    const uint32_t fa = pkmin3(tpk, u[0], u[1]), fb = pkmin3(u[2], u[3], u[4]);
-                    const uint32_t f = pkmin3(pkmin3(fa, u[5], u[6]), fb, u[7]);
-                    if (f != tpk) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int reg = 8 * qd + i;
-#pragma unroll
-                            for (int hf = 0; hf < 2; ++hf) {
-                                if (hf ? u[i] < thi : (u[i] & 0xFFFFu) < tlo) {
-                                    const int d = hf ? (int)(u[i] >> 16) - (int)PK_HI0 : (int)(u[i] & 0xFFFFu) - (int)PK_LO0;
-                                    if (d < -64) continue;      // not a dot product of 64 bits: never index anything with it
-                                    const uint32_t off = (uint32_t)((2 * j + hf) * 32 + (reg & 3) + 8 * (reg >> 2));
-                                    const uint64_t row = base + off;
-                                    if (row <= last_row) {
-                                        if constexpr (MODE == MODE_SELF) {
-                                            if (nhits == 0) { first_d = d; first_off = off; }
-                                            else tau_seen = emit_self<true>(p, q0 + ql, d + pc, row, tau_seen, pc);
-                                            nhits += 1;
-                                        } else {
-                                            emit<MODE>(p, q0 + ql, (uint32_t)(d + pc), row);
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            if constexpr (MODE == MODE_SELF) {
-                if (nhits) {
+    auto process_ring = [&](uint64_t st) {
+        const uint32_t reg = lane >> 1, hf = lane & 1;
+        const uint32_t off0 = (2 * (reg >> 4) + hf) * 32 + (reg & 3) + 8 * ((reg & 15) >> 2);
+        for (uint32_t e = 0; e < rcount; ++e) {
+            const uint32_t* const blk = ring + e * ENTRY;
+            const uint32_t bits = blk[reg], head = blk[32], tpk = blk[33];
+            const uint32_t ql = head & 0xFFFFu, off = off0 + 4 * (head >> 16);
+            const bool below = hf ? bits < (tpk & 0xFFFF0000u) : (bits & 0xFFFFu) < (tpk & 0xFFFFu);
+            const int d = hf ? (int)(bits >> 16) - (int)PK_HI0 : (int)(bits & 0xFFFFu) - (int)PK_LO0;
+            const uint64_t row = st * (32 * MT) + off;
+            // (d < -64 is no dot product of 64 bits: never turned into an index)
+            if (below && d >= -64 && row <= last_row) {
+                const int pc = lpop[ql];
+                if constexpr (MODE == MODE_SELF) {
                     pend.complete<true>(p, q0, lpop);
-                    pend.issue(p, q0, ql, first_d + pc, base + first_off, tau_seen);
+                    pend.issue(p, q0, ql, d + pc, row, unpack_threshold(tpk) + pc);
+                } else {
+                    emit<MODE>(p, q0 + ql, (uint32_t)(d + pc), row);
                 }
             }
+        }
+        rcount = 0;
+    };
+    // `mask`: the lanes whose fold differs from T (query g * 32 + (lane & 31), rows 4 * (lane >> 5) + ... of the step's tiles)
+    auto save_hits = [&](const Acc& acc, uint64_t mask, uint32_t tpk, uint32_t g, uint64_t st) {
+        while (mask) {                              // wave-uniform; more than one trip only when the ring fills up
+            const uint32_t room = RING_E - rcount;
+            if (room == 0) { process_ring(st); continue; }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const bool mine = ((mask >> lane) & 1) != 0 && rank < room;
+            if (mine) {
+                uint32_t* const blk = ring + (rcount + rank) * ENTRY;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4)
+                        *reinterpret_cast<float4*>(blk + 16 * j + i) = make_float4(acc.t[j][i], acc.t[j][i + 1], acc.t[j][i + 2], acc.t[j][i + 3]);
+                *reinterpret_cast<uint2*>(blk + 32) = make_uint2((g * 32 + r) | (h << 16), tpk);
+            }
+            const uint64_t taken = __builtin_amdgcn_ballot_w64(mine);
+            rcount += (uint32_t)__builtin_popcountll(taken);
+            mask &= ~taken;
         }
     };
 
@@ -658,15 +656,16 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         for (uint32_t g = 0; g + 2 < groups; g += 2) {
             by = lbl[(g + 2) * 64];                       // consumed by the stage before
             const uint32_t thrYn = lt[(g + 2) * 32];
-            if (__builtin_expect(stage(accX, accY, bx, thrY, mY) != 0, 0)) hits(accY, mY, thrY, g, step);
+            if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); __builtin_expect(mk != 0, 0)) save_hits(accY, mk, thrY, g, step);
             thrY = thrYn;
             bx = lbl[(g + 3) * 64];
             const uint32_t thrXn = lt[(g + 3) * 32];
-            if (__builtin_expect(stage(accY, accX, by, thrX, mX) != 0, 0)) hits(accX, mX, thrX, g + 1, step);
+            if (const uint64_t mk = stage(accY, accX, by, thrX, mX); __builtin_expect(mk != 0, 0)) save_hits(accX, mk, thrX, g + 1, step);
             thrX = thrXn;
         }
-        if (stage(accX, accY, bx, thrY, mY) != 0) hits(accY, mY, thrY, groups - 2, step);
-        if (last_fold(accX, thrX, mX) != 0) hits(accX, mX, thrX, groups - 1, step);
+        if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); mk != 0) save_hits(accY, mk, thrY, groups - 2, step);
+        if (const uint64_t mk = last_fold(accX, thrX, mX); mk != 0) save_hits(accX, mk, thrX, groups - 1, step);
+        if (rcount) process_ring(step);
         if constexpr (MODE == MODE_SELF) {
             if (refresh_now) *reinterpret_cast<uint4*>(lthr + fresh_index()) = make_uint4(fresh[0], fresh[1], fresh[2], fresh[3]);
             if (look) pend.complete<true>(p, q0, lpop);
@@ -676,6 +675,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
 }
 
 static int launch_pack(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
+    lds += MBLOCK / 64 * PK_RING_ENTRIES * PK_RING_ENTRY_DWORDS * sizeof(uint32_t);       // the waves' rings of saved accumulator blocks
     if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
     if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_pack_kernel<MODE_COLLECT>), grid, dim3(MBLOCK), lds, st, p, groups);
     else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_pack_kernel<MODE_STRETCH>), grid, dim3(MBLOCK), lds, st, p, groups);
