@@ -472,7 +472,20 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     constexpr uint32_t RING_E = PK_RING_ENTRIES, ENTRY = PK_RING_ENTRY_DWORDS;       // dwords: 32 registers | query, lane half | T | pad
     uint32_t* const ring = reinterpret_cast<uint32_t*>(lpop + groups * 32) + wave * (RING_E * ENTRY);
     uint32_t rcount = 0;                        // saved blocks in the ring (wave-uniform)
-    Pending pend;
+    // MODE_SELF: a candidate's list slot is requested here and its word stored once the slot is known -- at the lane's next
+    // candidate or at the end of the next step.  Its distance counts are NO-RETURN atomics (count[q][t] += 1 for every t in
+    // [hamming, threshold the compare ran under)): nobody waits for them; "k rows within t" is noticed by the CHECKER lanes
+    // below, which read one counter per step each and lower the live threshold with one atomicMin on the packed word.
+    // (The lane whose own increment crossed k used to do that: two returned atomics and a dependent chain of further ones per
+    //  candidate, ~3.6 us of wave time each -- the level design beat the single pass by 10 % at 100 M rows and by 40 % at 12.5 M.)
+    uint32_t pend_slot = 0, pend_lo = 0, pend_hi = 0x80000000u;        // pend_hi bit 31: nothing pending
+    auto pend_complete = [&]() {
+        if (!(pend_hi & 0x80000000u)) {
+            const uint32_t qi = q0 + (pend_hi >> 20);                   // query in chunk : 11 | hamming : 7 | row >> 32 : 12 ... see issue below
+            if (pend_slot < p.cap) p.cand[(uint64_t)qi * p.cap + pend_slot] = ((uint64_t)((pend_hi >> 12) & 0x7Fu) << 48) | ((uint64_t)(pend_hi & 0xFFFu) << 32) | pend_lo;
+            pend_hi = 0x80000000u;
+        }
+    };
     auto process_ring = [&](uint64_t st) {
         const uint32_t reg = lane >> 1, hf = lane & 1;
         const uint32_t off0 = (2 * (reg >> 4) + hf) * 32 + (reg & 3) + 8 * ((reg & 15) >> 2);
@@ -487,8 +500,14 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
             if (below && d >= -64 && row <= last_row) {
                 const int pc = lpop[ql];
                 if constexpr (MODE == MODE_SELF) {
-                    pend.complete<true>(p, q0, lpop);
-                    pend.issue(p, q0, ql, d + pc, row, unpack_threshold(tpk) + pc);
+                    pend_complete();
+                    const uint32_t qi = q0 + ql, hd = (uint32_t)(d + pc);
+                    const int tau_seen = unpack_threshold(tpk) + pc;
+                    pend_slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
+                    uint32_t* const counts = p.ghist + (uint64_t)qi * HB;
+                    for (int t = (int)hd; t < tau_seen; ++t) __hip_atomic_fetch_add(&counts[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: no-return form
+                    pend_lo = (uint32_t)row;
+                    pend_hi = (ql << 20) | (hd << 12) | (uint32_t)(row >> 32);       // rows < 2^44
                 } else {
                     emit<MODE>(p, q0 + ql, (uint32_t)(d + pc), row);
                 }
@@ -628,17 +647,35 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     const bool refresh = MODE == MODE_SELF && wave * 256 + lane * 4 < groups * 32 && q0 + wave * 256 + lane * 4 < p.nq_pad;
     // a step is 128 rows here (64 in mfma_scan_kernel): look half as many steps apart for the same rows per look
     const uint32_t refresh_mask = (groups >= 32 ? 1u : groups >= 16 ? 2u : groups >= 8 ? 4u : groups >= 4 ? 8u : 16u) * ((p.refresh_steps + 1) / 2) - 1u;
+    // CHECKERS (MODE_SELF): task (query, j) asks "do k appended rows lie within tau_q - j?", j = 1..4, by reading count[q][tau_q - j]
+    // at the start of a look step and lowering the live threshold at its end.  64 tasks per wave and look: the first
+    // `slices` waves of the grid take one slice each; a grid with fewer waves rotates through the slices step by step.
+    const uint32_t slices = groups * 32 * 4 / 64, nwaves = gridDim.x * (MBLOCK / 64);
+    const uint32_t gw = blockIdx.x * (MBLOCK / 64) + wave_s;
     uint32_t trip = 0;
     for (; step < nsteps; step += stride, ++trip) {
         const uint64_t ns = step + stride < nsteps ? step + stride : step;
         uint32_t fresh[4] = {0u, 0u, 0u, 0u};
         const bool look = trip < 4 || (trip & refresh_mask) == 0;
         const bool refresh_now = refresh && look;
+        uint32_t chk_count = 0, chk_what = ~0u;       // chk_what: query in chunk | hamming level << 16, ~0: no task
         if constexpr (MODE == MODE_SELF) {
             if (refresh_now) {
                 const float* const src = p.thr_live + q0 + fresh_index();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fresh[i] = live_packed(src + i);
+            }
+            const uint32_t slice = nwaves >= slices ? gw : (gw + trip * nwaves) % slices;
+            if (look && slice < slices) {
+                uint32_t z = 0;
+                asm volatile("" : "+v"(z));
+                const uint32_t task = slice * 64 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+                const uint32_t ql = task >> 2, tpk = lthr[ql];
+                const int level = unpack_threshold(tpk) + lpop[ql] - 1 - (int)(task & 3);
+                if (tpk != 0 && level >= 0 && q0 + ql < p.nq_pad) {
+                    chk_what = ql | ((uint32_t)level << 16);
+                    chk_count = (uint32_t)__hip_atomic_load(reinterpret_cast<const int*>(p.ghist + (uint64_t)(q0 + ql) * HB + level), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
 #pragma unroll
@@ -665,13 +702,18 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         }
         if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); mk != 0) save_hits(accY, mk, thrY, groups - 2, step);
         if (const uint64_t mk = last_fold(accX, thrX, mX); mk != 0) save_hits(accX, mk, thrX, groups - 1, step);
+        // what the PREVIOUS step's appends returned (issued a whole step ago: no wait), then this step's blocks
+        if constexpr (MODE == MODE_SELF) pend_complete();
         if (rcount) process_ring(step);
         if constexpr (MODE == MODE_SELF) {
+            if (chk_what != ~0u && chk_count >= p.k) {
+                const uint32_t ql = chk_what & 0xFFFFu;
+                atomicMin(reinterpret_cast<uint32_t*>(p.thr_live) + q0 + ql, pack_threshold((int)(chk_what >> 16) - lpop[ql]));
+            }
             if (refresh_now) *reinterpret_cast<uint4*>(lthr + fresh_index()) = make_uint4(fresh[0], fresh[1], fresh[2], fresh[3]);
-            if (look) pend.complete<true>(p, q0, lpop);
         }
     }
-    if constexpr (MODE == MODE_SELF) pend.complete<true>(p, q0, lpop);
+    if constexpr (MODE == MODE_SELF) pend_complete();
 }
 
 static int launch_pack(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
