@@ -467,10 +467,12 @@ def other_configs(engine, args):
     from iscc_search_amd import _lib
 
     out = {}
+    # sized from --rows: the default 100 M-row run carries config 3 at its full size and config 5's table at 10 M rows
+    rows3, rows5 = args.rows, max(1, args.rows // 10)
     cases = (
-        ("config3", "100 M x 256-bit ISCC-UNITs, NPHD, 1 024 queries, k = 10", dict(rows=100_000_000, nbytes=32, nphd=True, key_words=1, nq=1024, k=10, steps=3)),
-        ("config5_shape", "10 M x 128-bit chunk fingerprints, 128-bit keys, 512 queries, k = 400 (one of config 5's three tables)",
-         dict(rows=10_000_000, nbytes=16, nphd=False, key_words=2, nq=512, k=400, steps=5)),
+        ("config3", f"{rows3} x 256-bit ISCC-UNITs, NPHD, 1 024 queries, k = 10", dict(rows=rows3, nbytes=32, nphd=True, key_words=1, nq=1024, k=10, steps=3)),
+        ("config5_shape", f"{rows5} x 128-bit chunk fingerprints, 128-bit keys, 512 queries, k = 400 (one of config 5's three tables)",
+         dict(rows=rows5, nbytes=16, nphd=False, key_words=2, nq=512, k=400, steps=5)),
     )
     for name, what, c in cases:
         words = (c["nbytes"] + 7) // 8

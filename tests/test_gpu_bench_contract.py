@@ -52,3 +52,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cpu["py_memory_style"]["value"] > 0 and cpu["usearch"].startswith("unavailable")
     # the oracle's answers of the CPU leg were compared bit for bit with the GPU's
     assert out["parity_checked_queries"] == 64
+    # round 3: the unsettled figure beside `value`, the memory picture of the timed kernel, no field that
+    # reads as bytes the matrix-core kernel never moved, and BASELINE configs 3 and 5 in the same run
+    assert out["value_unsettled"] > 0 and "settle_steps" in out
+    assert "whole_step_algorithmic_GBs" not in out and "algorithmic_bytes_per_launch" not in roof and roof["section8d_bytes_equivalent"] > 0
+    assert roof["traffic"] is None or 0 < roof["hbm_traffic_frac"] < 1.0
+    assert "algorithmic_bytes_per_launch" in stream
+    for name, bits in (("config3", 256), ("config5_shape", 128)):
+        oc = out["other_configs"][name]
+        assert oc["queries_per_s"] > 0 and oc["parity_checked_queries"] == 4 and str(bits) in oc["workload"]
+        assert oc["roofline"] is None or 0 < oc["roofline"]["frac"] <= 1.0

@@ -25,7 +25,7 @@ commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 # kernel name prefixes: levels (<.., 2>) and collect (<.., 3>) are two instantiations of one body; the streaming leg keeps to the collect launches
-DOMINANT = {"mfma": "mfma_scan_kernel<1,", "valu": "scan_adapt_kernel<8,", "streaming": "scan_adapt_kernel<8, 3>", "config3": "mfma_scan_kernel<4,"}
+DOMINANT = {"mfma": "mfma_pack_kernel<", "valu": "scan_adapt_kernel<8,", "streaming": "scan_adapt_kernel<8, 3>", "config3": "mfma_scan_kernel<4,"}
 
 
 def one(pattern):
@@ -94,11 +94,12 @@ sq = {"commit": commit, "command": "tools/profile_round.sh: rocprofv3 --pmc SQ_W
       "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py ... --steps 3",
       "notes": "SQ_* wave counters are in quad-cycles summed over all waves; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over the 1 024 SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs "
                "(MI355X_MICROARCH.md)", "kernels": {}}
-for regime in ("mfma", "valu"):
+DOMINANT_SQ = dict(DOMINANT, mfma_unpacked="mfma_scan_kernel<1,")        # the round-2 kernel, same box, option mfma_pack=0
+for regime in ("mfma", "valu", "mfma_unpacked"):
     cc = one(f"prof_sq_{regime}/**/*counter_collection.csv")
     if not cc:
         continue
-    c = dispatches(cc, DOMINANT[regime])
+    c = dispatches(cc, DOMINANT_SQ[regime])
     if not c.get("SQ_WAVE_CYCLES"):
         continue
     mean = {k: sum(v) / len(v) for k, v in c.items() if not k.startswith("_")}
@@ -108,7 +109,13 @@ for regime in ("mfma", "valu"):
                "valu_wave_instructions_per_simd_cycle": mean["SQ_INSTS_VALU"] / 1024 / cycles_per_xcd,
                "valu_issue_occupancy_at_4_cycles_per_instruction": mean["SQ_INSTS_VALU"] * 4 / 1024 / cycles_per_xcd,
                "matrix_pipe_busy_fraction": mean["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cycles_per_xcd}
-    sq["kernels"][DOMINANT[regime]] = {"dispatches": len(c["_ms"]), "mean_per_dispatch": mean, "derived": derived}
+    entry = {"dispatches": len(c["_ms"]), "mean_per_dispatch": mean, "derived": derived}
+    # the second pass of the same kernel (other counters, own run): instruction mix per wave-level MFMA
+    cc2 = one(f"prof_sq2_{regime}/**/*counter_collection.csv")
+    if cc2:
+        c2 = dispatches(cc2, DOMINANT_SQ[regime])
+        entry["second_pass_mean_per_dispatch"] = {k: sum(v) / len(v) for k, v in c2.items() if not k.startswith("_")}
+    sq["kernels"][DOMINANT_SQ[regime] + (" [option mfma_pack=0]" if regime == "mfma_unpacked" else "")] = entry
 json.dump(sq, open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
 print(json.dumps({k: {kk: round(vv, 4) for kk, vv in v["derived"].items()} for k, v in sq["kernels"].items()}, indent=1))
 print({k: (round(v["raw_bytes_per_launch"] / 1e9, 3), v["dispatches"]) for k, v in fetch["regimes"].items()})
