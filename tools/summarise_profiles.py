@@ -82,7 +82,8 @@ for regime, key in (("mfma", "mfma"), ("valu", "valu_blocked"), ("streaming", "v
         roof = json.load(f)["roofline"]          # the same run's own launch accounting
     entry = {
         "kernel": DOMINANT[regime], "dispatches": n_launch, "FETCH_SIZE_KB_per_dispatch": kb, "kernel_ms_per_dispatch_under_pmc": c["_ms"],
-        "triples_per_launch": roof["triples_per_launch"], "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+        "triples_per_launch": roof["triples_per_launch"],
+        "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch", roof.get("rows_bytes_per_launch")),   # matrix cores: the rows, once
         "raw_bytes_per_launch": sum(kb) / n_launch * 1024,
         "corrected_bytes_per_launch": sum(kb) / n_launch * 1024 * 2,
     }
