@@ -450,6 +450,16 @@ class HipIndex:
                 table.save(os.path.join(path, "units", unit_type))
             for sp_type, table in self._sp_tables.items():
                 table.save(os.path.join(path, "simprints", sp_type))
+                if writer:
+                    # the per-asset chunk lists are host state every rank keeps whole: written once, by rank 0, beside the table
+                    # shards, so that a restore reads a file instead of gathering every shard's rows to every rank
+                    pairs = [pair for chunks in self._sp_assets.get(sp_type, {}).values() for pair in chunks]
+                    nb = table.ndim // 8
+                    ptrs = np.frombuffer(b"".join(ptr for _, ptr in pairs), dtype=np.uint8).reshape(len(pairs), 16)
+                    sps = np.frombuffer(b"".join(sp for sp, _ in pairs), dtype=np.uint8).reshape(len(pairs), nb)
+                    tmp = os.path.join(path, "simprints", sp_type, "host_chunks.tmp.npz")
+                    np.savez(tmp, pointers=ptrs, simprints=sps)
+                    os.replace(tmp, os.path.join(path, "simprints", sp_type, "host_chunks.npz"))
             if writer:
                 meta = {
                     "format": 1, "realm_id": self._realm_id, "assets": len(self._assets),
@@ -492,11 +502,16 @@ class HipIndex:
         for sp_type, ndim in meta["simprint_types"].items():
             table = idx._sp_table(sp_type, ndim)
             table.load(os.path.join(path, "simprints", sp_type))
-            # the host-side per-asset chunk lists are derived from the stored rows (of every shard: they are host state
-            # every rank keeps whole)
-            rows = list(table.rows())
-            if hasattr(engine, "all_gather_object"):
-                rows = sorted(r for part in engine.all_gather_object(rows) for r in part)
+            # the host-side per-asset chunk lists (host state every rank keeps whole): from the file rank 0 wrote; snapshots of
+            # before that file existed derive them from the stored rows (of every shard, gathered)
+            host_chunks = os.path.join(path, "simprints", sp_type, "host_chunks.npz")
+            if os.path.exists(host_chunks):
+                with np.load(host_chunks) as z:
+                    rows = sorted((z["pointers"][i].tobytes(), z["simprints"][i].tobytes()) for i in range(len(z["pointers"])))
+            else:
+                rows = list(table.rows())
+                if hasattr(engine, "all_gather_object"):
+                    rows = sorted(r for part in engine.all_gather_object(rows) for r in part)
             for ckey, sp_bytes in rows:
                 body = unpack_chunk_pointer(ckey)[0]
                 idx._sp_assets[sp_type].setdefault(body, []).append((sp_bytes, ckey))
@@ -526,18 +541,26 @@ class HipIndexManager:
     creates a ``HipEngine`` and raises if the HIP library or the GPU is missing.  There is no CPU fallback.
     """
 
-    def __init__(self, uri="hip:///", engine=None, options=None):
-        # type: (str, object | None, HipOptions | None) -> None
+    def __init__(self, uri="hip:///", engine=None, options=None, shard_engine_factory=None):
+        # type: (str, object | None, HipOptions | None, str | None) -> None
         parsed = urlparse(uri)
         if parsed.scheme != "hip":
             raise ValueError(f"HipIndexManager requires a hip:// URI, got '{uri}'")
         qs = parse_qs(parsed.query)
         self.device_id = int(qs.get("device", ["0"])[0])
-        # hip:///?devices=N  -> the index row-sharded over N GPUs: one process per GPU under torch.distributed, every
-        #                       rank runs the same calls (iscc_search_amd/sharded_engine.py)
+        # hip:///?devices=N  -> the index row-sharded over N GPUs, one process per GPU (iscc_search_amd/sharded_engine.py).
+        #   * constructed where NO torch.distributed group exists (the reference's server / CLI: one process): this process
+        #     becomes the leader, starts the N - 1 other ranks itself and broadcasts every call to them (shard_front.py);
+        #     `backend=gloo` / `same_gpu=1` in the query select the rehearsal transport (CPU tests, ranks sharing one GPU)
+        #   * constructed on every rank of a running group of N (torch.distributed.run): SPMD, every rank makes the same calls
         self.devices = int(qs.get("devices", ["1"])[0])
         if self.devices < 1:
             raise ValueError(f"devices must be >= 1, got {self.devices}")
+        self._uri = uri
+        self._shard_backend = qs.get("backend", ["nccl"])[0]
+        self._shard_same_gpu = qs.get("same_gpu", ["0"])[0] == "1"
+        self._shard_engine_factory = shard_engine_factory
+        self._leader = None
         # hip:///            -> volatile (like memory://)
         # hip:///abs/path    -> snapshots under that directory: loaded lazily, written by flush()/close()
         self.base_path = parsed.path if parsed.path not in ("", "/") else None
@@ -557,6 +580,23 @@ class HipIndexManager:
                 if INDEX_NAME_RE.match(name) and os.path.exists(os.path.join(self.base_path, name, "index.json")):
                     self._on_disk.add(name)
 
+    def _lead(self):
+        """The leader front of a sharded index opened by ONE process (None: unsharded, an injected engine, or SPMD under a launcher)."""
+        if self.devices == 1 or self._engine is not None:
+            return None
+        if self._leader is None:
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                return None
+            from iscc_search_amd.shard_front import ShardLeader
+
+            with self._lock:
+                if self._leader is None:
+                    self._leader = ShardLeader(self._uri, self.devices, backend=self._shard_backend, engine_factory=self._shard_engine_factory,
+                                               same_gpu=self._shard_same_gpu)
+        return self._leader
+
     def _get_engine(self):
         if self._engine is None:
             from iscc_search_amd.engine import HipEngine   # raises loudly without library / GPU
@@ -568,8 +608,8 @@ class HipIndexManager:
 
                 if not dist.is_initialized() or dist.get_world_size() != self.devices:
                     raise ValueError(
-                        f"hip:///?devices={self.devices} needs {self.devices} processes under torch.distributed (one per GPU: "
-                        f"python -m torch.distributed.run --nproc-per-node {self.devices} ...), initialised BEFORE the index is opened"
+                        f"hip:///?devices={self.devices}: this rank's engine needs the process group of {self.devices} ranks (one per GPU); "
+                        f"a single calling process gets it from shard_front.ShardLeader, a launcher from torch.distributed.run"
                     )
                 local = int(os.environ.get("LOCAL_RANK", dist.get_rank()))
                 self._engine = ShardedEngine(HipEngine(local), device=f"cuda:{local}")
@@ -595,9 +635,27 @@ class HipIndexManager:
         with open(os.path.join(self.base_path, name, "index.json")) as f:
             return json.load(f).get("assets", 0)
 
+    # Every public method runs `_guarded`:
+    #   * a sharded index opened by ONE process hands the call to the leader front, which broadcasts it to the shard workers and
+    #     runs it on this process's own rank-0 manager (shard_front.py) -- the leader's lock orders all requests;
+    #   * a sharded index under a launcher (SPMD) takes `_spmd` around the WHOLE method: flush, close, the lazy snapshot load in
+    #     `_index` and delete_index reach collectives just as add / search do;
+    #   * one GPU: no extra lock, searches of concurrent callers are combined by the engine.
+    def _guarded(self, method, impl, *args, **kwargs):
+        lead = self._lead()
+        if lead is not None:
+            return lead.call(method, *args, **kwargs)
+        if self._spmd is not None:
+            with self._spmd:
+                return impl(*args, **kwargs)
+        return impl(*args, **kwargs)
+
     def flush(self):
         # type: () -> None
         """Write every modified index to its snapshot directory (no-op for volatile managers)."""
+        return self._guarded("flush", self._flush)
+
+    def _flush(self):
         if not self.base_path:
             return
         with self._lock:
@@ -609,11 +667,17 @@ class HipIndexManager:
     # -- protocol ----------------------------------------------------------------------------------
     def list_indexes(self):
         # type: () -> List[IsccIndex]
+        return self._guarded("list_indexes", self._list_indexes)
+
+    def _list_indexes(self):
         with self._lock:
             return [IsccIndex(name=n, assets=self._asset_count(n), size=0) for n in self._names()]
 
     def create_index(self, index):
         # type: (IsccIndex) -> IsccIndex
+        return self._guarded("create_index", self._create_index, index)
+
+    def _create_index(self, index):
         validate_index_name(index.name)
         with self._lock:
             if index.name in self._indexes or index.name in self._on_disk:
@@ -623,6 +687,9 @@ class HipIndexManager:
 
     def get_index(self, name):
         # type: (str) -> IsccIndex
+        return self._guarded("get_index", self._get_index, name)
+
+    def _get_index(self, name):
         with self._lock:
             if name not in self._indexes and name not in self._on_disk:
                 raise FileNotFoundError(f"Index '{name}' not found")
@@ -630,26 +697,33 @@ class HipIndexManager:
 
     def delete_index(self, name):
         # type: (str) -> None
+        return self._guarded("delete_index", self._delete_index, name)
+
+    def _delete_index(self, name):
         with self._lock:
             if name not in self._indexes and name not in self._on_disk:
                 raise FileNotFoundError(f"Index '{name}' not found")
             if name in self._indexes:
                 self._indexes.pop(name).close()
             if name in self._on_disk:
-                shutil.rmtree(os.path.join(self.base_path, name), ignore_errors=True)
+                if getattr(self._engine, "rank", 0) == 0:          # one snapshot directory, shared by the ranks of a node
+                    shutil.rmtree(os.path.join(self.base_path, name), ignore_errors=True)
                 self._on_disk.discard(name)
 
     def add_assets(self, index_name, assets):
         # type: (str, List[IsccEntry]) -> List[IsccAddResult]
+        return self._guarded("add_assets", self._add_assets, index_name, assets)
+
+    def _add_assets(self, index_name, assets):
         with self._lock:
             idx = self._index(index_name)
-        if self._spmd is not None:
-            with self._spmd:
-                return idx.add_assets(assets)
         return idx.add_assets(assets)
 
     def get_asset(self, index_name, iscc_id):
         # type: (str, str) -> IsccEntry
+        return self._guarded("get_asset", self._get_asset, index_name, iscc_id)
+
+    def _get_asset(self, index_name, iscc_id):
         with self._lock:
             idx = self._index(index_name)
         try:
@@ -659,23 +733,33 @@ class HipIndexManager:
 
     def search_assets(self, index_name, query, limit=100):
         # type: (str, IsccQuery, int) -> IsccSearchResult
+        return self._guarded("search_assets", self._search_assets, index_name, query, limit)
+
+    def _search_assets(self, index_name, query, limit=100):
         with self._lock:
             idx = self._index(index_name)
         try:
-            if self._spmd is not None:
-                with self._spmd:
-                    return idx.search_assets(query, limit)
             return idx.search_assets(query, limit)
         except FileNotFoundError:
             raise FileNotFoundError(f"Asset '{query.iscc_id}' not found in index '{index_name}'")
 
     def close(self):
         # type: () -> None
+        if self._leader is not None:
+            self._leader.close()
+            self._closed = True
+            return
+        if self._spmd is not None:
+            with self._spmd:
+                return self._close()
+        return self._close()
+
+    def _close(self):
         with self._lock:
             if self._closed:
                 return
             self._closed = True
-            self.flush()
+            self._flush()
             for idx in self._indexes.values():
                 idx.close()
             self._indexes.clear()

@@ -17,10 +17,19 @@ contract (``iscc_search/indexes/usearch/manager.py:43-46``); what this replaces 
 * ``contains`` / ``get`` / ``size`` / ``remove``'s count are answered by the owner and combined with one small
   all-reduce each -- the key -> rank map is the hash itself, no host table is needed.
 
-SPMD discipline (as for any ``torch.distributed`` program): every rank must make the same calls in the same order --
-``HipIndexManager`` serialises the calls that reach the engine -- and an exception raised on ONE rank only (a device
-allocation failing on one GPU) leaves the others waiting in their collective: run the ranks under a launcher that tears the
-job down when one exits (``torch.distributed.run`` does).
+SPMD discipline (as for any ``torch.distributed`` program): every rank must make the same calls in the same order.  Two ways
+to get that:
+
+* ONE calling process (the reference's server and CLI): ``HipIndexManager("hip:///path?devices=N")`` constructed where no
+  process group exists becomes the leader of ``shard_front.ShardLeader``, starts the other ranks itself and broadcasts every
+  protocol call to them under one lock -- the order is the leader's, whatever the caller's threads do;
+* ``python -m torch.distributed.run --nproc-per-node N script.py`` where the script itself makes identical calls on every rank
+  (``bench.py``): then each rank's manager holds one lock around EVERY protocol method (also flush, close, the lazy snapshot
+  load and delete_index: all of them reach collectives), which keeps one rank's threads from interleaving two requests'
+  collectives -- it cannot order two threads the same way on two ranks, so such a script must issue its calls from one thread.
+
+An exception raised on ONE rank only (a device allocation failing on one GPU) leaves the others waiting in their collective
+until the group's timeout: the leader's watchdog (first way) or the launcher (second way) tears the job down.
 """
 
 import os
@@ -43,8 +52,8 @@ def owner_of(route_words, world_size):
 class ShardedEngine:
     """Engine facade over one local engine per rank (``HipEngine`` in production)."""
 
-    def __init__(self, local_engine, ops_factory=None, group=None, device=None):
-        # type: (object, object | None, object | None, object | None) -> None
+    def __init__(self, local_engine, ops_factory=None, group=None, device=None, ctrl_group=None):
+        # type: (object, object | None, object | None, object | None, object | None) -> None
         import torch.distributed as dist
 
         if not dist.is_initialized():
@@ -52,6 +61,9 @@ class ShardedEngine:
         self.dist = dist
         self.local = local_engine
         self.group = group
+        # small host-side collectives (owner lookups, counts, snapshot barriers) go over `ctrl_group` when given -- a gloo group
+        # beside an RCCL data group: no staging through the GPU, no RCCL launch for 8 bytes
+        self.ctrl_group = ctrl_group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device
@@ -70,15 +82,16 @@ class ShardedEngine:
         a = np.ascontiguousarray(arr)
         view = a.view(np.int64) if a.dtype == np.uint64 else a
         t = torch.from_numpy(view.copy())
-        if self.dist.get_backend(self.group) == "nccl":
+        group = self.ctrl_group if self.ctrl_group is not None else self.group
+        if self.dist.get_backend(group) == "nccl":
             t = t.to(self.device if self.device is not None else "cuda")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX, group=self.group)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX, group=group)
         out = t.cpu().numpy()
         return out.view(np.uint64) if a.dtype == np.uint64 else out.astype(a.dtype, copy=False)
 
     def all_gather_object(self, obj):
         out = [None] * self.world_size
-        self.dist.all_gather_object(out, obj, group=self.group)
+        self.dist.all_gather_object(out, obj, group=self.ctrl_group if self.ctrl_group is not None else self.group)
         return out
 
     # -- HipEngine duck type ---------------------------------------------------------------------------
