@@ -202,6 +202,12 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
  * Replaces count_doc_freq (lmdb_ops.py:139-166, called per matched simprint from usearch/index.py:1395-1403). */
 int isccsearch_doc_freq(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                         const uint8_t* q_nbytes, uint32_t dup_limit, uint32_t* out_freq);
+/* The same, and out_collisions[q] = how many rows equal to code q were looked at (<= dup_limit).  What a table SHARDED by
+ * asset needs (sharded_engine.py: an asset's chunks share a rank): when the collisions of all shards together stay within
+ * dup_limit -- the normal case -- the shards' distinct-asset counts simply add; only otherwise is the merged list needed.
+ * Same reference call site: count_doc_freq, lmdb_ops.py:139-166. */
+int isccsearch_doc_freq_counted(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                                const uint8_t* q_nbytes, uint32_t dup_limit, uint32_t* out_freq, uint32_t* out_collisions);
 
 /* Document frequency of STORED codes, by key: out_freq[i] = frequency (as isccsearch_doc_freq defines it) of
  * the code stored under keys[i], 0 when the key is absent.  Served from a per-segment frequency column that is

@@ -27,7 +27,7 @@ EXPORTS = (
     "isccsearch_stats_get", "isccsearch_table_open", "isccsearch_table_drop", "isccsearch_reserve",
     "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
     "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
-    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_search_many", "isccsearch_doc_freq", "isccsearch_get_freq",
+    "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_search_many", "isccsearch_doc_freq", "isccsearch_doc_freq_counted", "isccsearch_get_freq",
     "isccsearch_search_device", "isccsearch_search_within_device", "isccsearch_merge_device",
     "isccsearch_search_device_async", "isccsearch_merge_device_after",
 )
@@ -140,6 +140,7 @@ def load_library():
         "isccsearch_search_within": (i, [vp, u32, u32, u64p, u8p, u32, u32, u64p, u32p, u16p, u32p]),
         "isccsearch_search_many": (i, [vp, u32, ctypes.POINTER(Request)]),
         "isccsearch_doc_freq": (i, [vp, u32, u32, u64p, u8p, u32, u32p]),
+        "isccsearch_doc_freq_counted": (i, [vp, u32, u32, u64p, u8p, u32, u32p, u32p]),
         "isccsearch_get_freq": (i, [vp, u32, u64, u64p, u32, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
         "isccsearch_search_within_device": (i, [vp, u32, u32, u64p, u8p, u32, u32, vp, vp]),

@@ -1479,7 +1479,7 @@ int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const 
 static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                          const uint8_t* q_nbytes, uint32_t k,
                          uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count,
-                         int radius = -1, uint32_t* out_freq = nullptr) {
+                         int radius = -1, uint32_t* out_freq = nullptr, uint32_t* out_collisions = nullptr) {
     Table* tp;
     int rc = get_table(h, table, tp);
     if (rc) return rc;
@@ -1508,7 +1508,8 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         // result block {records [m][k] | counts [m] | flags [<= m + 15]} on the device and, mirrored, in pinned memory
         const size_t rec_bytes = (size_t)m * k * sizeof(isk::Record);
         const size_t flag_slots = (size_t)m + 16;                       // nq_pad <= m + 15 for every T_q
-        const size_t block_bytes = rec_bytes + ((size_t)m + flag_slots) * sizeof(uint32_t);
+        // (+ m counts behind the flags when a document-frequency call also wants the lists' lengths)
+        const size_t block_bytes = rec_bytes + ((size_t)m + flag_slots + (out_collisions ? m : 0)) * sizeof(uint32_t);
         if ((rc = h->d_block.ensure(block_bytes))) return rc;
         if ((rc = h->p_block.ensure(block_bytes))) return rc;
         const isk::Record* const p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p);
@@ -1534,6 +1535,7 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 isk::DistinctParams dp{d_rec, d_cnt, h->d_freq.p, k, (uint32_t)t.key_words};
                 hipLaunchKernelGGL(isk::distinct_kernel, dim3(m), dim3(isk::BLOCK), 0, h->stream, dp);
                 HIPOK(hipGetLastError());
+                if (out_collisions) HIPOK(hipMemcpyAsync(p_cnt + m + flag_slots, d_cnt, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
                 HIPOK(hipMemcpyAsync(p_cnt, h->d_freq.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
                 return 0;
             }
@@ -1576,6 +1578,8 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         if (out_freq) {
             if (batch.jobs.empty()) for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = 0;
             else for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = p_cnt[i];
+            if (out_collisions)
+                for (uint32_t i = 0; i < m; ++i) out_collisions[order[pos + i]] = batch.jobs.empty() ? 0 : p_cnt[m + flag_slots + i];
         } else {
             unpack_records(p_rec, p_cnt, m, k, t.key_words, &order[pos], out_keys, out_hamming, out_prefix_bits, out_count);
         }
@@ -1838,6 +1842,17 @@ int isccsearch_doc_freq(isccsearch_handle* h, uint32_t table, uint32_t nq, const
     std::lock_guard<std::mutex> lk(h->mu);
     h->stats.searches += 1;
     return search_locked(h, table, nq, q_words, q_nbytes, dup_limit, nullptr, nullptr, nullptr, nullptr, 0, out_freq);
+}
+
+int isccsearch_doc_freq_counted(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                                const uint8_t* q_nbytes, uint32_t dup_limit, uint32_t* out_freq, uint32_t* out_collisions) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (dup_limit < 1 || dup_limit > ISCCSEARCH_MAX_K) return fail(-EINVAL, "dup_limit %u outside 1..ISCCSEARCH_MAX_K (%d)", dup_limit, ISCCSEARCH_MAX_K);
+    if (nq == 0) return 0;
+    if (!q_words || !out_freq || !out_collisions) return fail(-EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->stats.searches += 1;
+    return search_locked(h, table, nq, q_words, q_nbytes, dup_limit, nullptr, nullptr, nullptr, nullptr, 0, out_freq, out_collisions);
 }
 
 static int search_device_impl(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,

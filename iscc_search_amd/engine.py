@@ -338,6 +338,22 @@ class HipTable:
             )
         return out
 
+    def doc_freq_counted(self, q_words, q_nbytes=None, dup_limit=1000):
+        # type: (np.ndarray, np.ndarray | None, int) -> tuple
+        """``doc_freq`` and, beside it, how many colliding rows each count was taken over (<= dup_limit) -> (uint32 [nq], uint32 [nq])."""
+        q_words = self._words(q_words)
+        nq = q_words.shape[0]
+        q_nbytes = self._nbytes(q_nbytes, nq)
+        freq, coll = np.zeros(nq, dtype=np.uint32), np.zeros(nq, dtype=np.uint32)
+        if nq:
+            _lib.check(
+                self.engine._lib.isccsearch_doc_freq_counted(
+                    self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8),
+                    int(dup_limit), _lib.ptr(freq, ctypes.c_uint32), _lib.ptr(coll, ctypes.c_uint32),
+                )
+            )
+        return freq, coll
+
     def get_freq(self, keys, dup_limit=1000):
         # type: (np.ndarray, int) -> np.ndarray
         """

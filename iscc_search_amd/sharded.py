@@ -78,6 +78,10 @@ class HipShardOps:
             return self.table.search(q_words, q_nbytes, k)
         return self.table.search_within(q_words, q_nbytes, k, max_hamming)
 
+    def local_doc_freq(self, q_words, q_nbytes, dup_limit):
+        """This shard's (distinct assets, colliding rows looked at) per code: lookup and reduction on the device."""
+        return self.table.doc_freq_counted(q_words, q_nbytes, dup_limit)
+
     def merge(self, gathered, n_lists, nq, k):
         """Merge ordered behind torch's current stream (where the gathered blocks were produced): one copy, one synchronisation."""
         rec_bytes, blk = block_bytes(nq, k)
@@ -92,13 +96,16 @@ class ShardedTable:
     Every rank calls ``search`` with the SAME queries and gets the SAME global top-k back.
     """
 
-    def __init__(self, ops, group=None, always_gather=False):
+    def __init__(self, ops, group=None, always_gather=False, assets_share_a_rank=False):
         import torch.distributed as dist
 
         self.dist = dist
         self.ops = ops
         self.group = group
         self.always_gather = always_gather   # run the collective even with one rank (rehearsal on one GPU)
+        # rows routed by the asset word of their key (sharded_engine.ShardedHipTable): per-shard document frequencies add.
+        # Row-RANGE shards (bench.py, the engine-level tests) may split an asset's chunks: the merged list is reduced instead
+        self.assets_share_a_rank = assets_share_a_rank
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -118,15 +125,50 @@ class ShardedTable:
     def doc_freq(self, q_words, q_nbytes=None, dup_limit=1000):
         # type: (np.ndarray, np.ndarray | None, int) -> np.ndarray
         """
-        Distinct assets among the first ``dup_limit`` collisions of each code across ALL shards.  An asset's chunks
-        may sit on different ranks, so the per-shard counts cannot be added: the merged collision list is reduced.
+        Distinct assets among the first ``dup_limit`` collisions of each code across ALL shards (``count_doc_freq``,
+        ``lmdb_ops.py:139-166``).
+
+        Rows are routed by their ASSET word, so an asset's chunks share a rank and the shards' distinct-asset counts ADD --
+        as long as every collision is looked at, i.e. the collisions of all shards together stay within ``dup_limit`` (the
+        normal case: each shard reduces its own list on the device, one small all-reduce sums counts and lengths).  A code
+        with more collisions than that is cut at ``dup_limit`` in key order ACROSS the shards: for those codes only, the
+        merged collision list is reduced (the lists are ordered by key, so distinct assets are the changes of the asset word).
         """
-        keys, _, _, cnt = self.search_within(q_words, q_nbytes, dup_limit, 0)
-        out = np.zeros(len(cnt), dtype=np.uint32)
-        for q, c in enumerate(cnt):
-            assets = keys[q, :c, 0] if keys.ndim == 3 else keys[q, :c]
-            out[q] = len(np.unique(assets))
+        local = getattr(self.ops, "local_doc_freq", None)
+        if self.world_size == 1 and not self.always_gather and local is not None:
+            return local(q_words, q_nbytes, dup_limit)[0]
+        nq = q_words.shape[0]
+        if local is None or not self.assets_share_a_rank:
+            slow = np.arange(nq)
+            out = np.zeros(nq, dtype=np.uint32)
+        else:
+            freq, coll = local(q_words, q_nbytes, dup_limit)
+            both = self._all_reduce_sum(np.concatenate([freq.astype(np.int64), coll.astype(np.int64)]))
+            out = both[:nq].astype(np.uint32)
+            slow = np.nonzero(both[nq:] > dup_limit)[0]          # the same on every rank: they all take the slow path together
+        if len(slow):
+            qn = None if q_nbytes is None else np.ascontiguousarray(np.asarray(q_nbytes)[slow])
+            keys, _, _, cnt = self.search_within(np.ascontiguousarray(q_words[slow]), qn, dup_limit, 0)
+            assets = keys[..., 0] if keys.ndim == 3 else keys
+            valid = np.arange(assets.shape[1])[None, :] < cnt[:, None]
+            change = np.ones_like(valid)
+            change[:, 1:] = assets[:, 1:] != assets[:, :-1]
+            out[slow] = (valid & change).sum(axis=1).astype(np.uint32)
         return out
+
+    def _all_reduce_sum(self, arr):
+        # type: (np.ndarray) -> np.ndarray
+        """Small host array summed over the ranks (the ops object may bring its own transport: ``ShardedEngine.all_reduce``)."""
+        reducer = getattr(self.ops, "all_reduce_sum", None)
+        if reducer is not None:
+            return reducer(arr)
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64).copy())
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.to(getattr(self.ops, "device", "cuda"))
+        self.dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
 
     def _search(self, q_words, q_nbytes, k, max_hamming):
         out = self._exchange(q_words, q_nbytes, k, max_hamming, {})

@@ -129,7 +129,10 @@ class ShardedHipTable:
         self.key_words = local_table.key_words
         self.max_bytes = local_table.max_bytes
         self.max_words = local_table.max_words
-        self._sharded = ShardedTable(engine._ops_factory(local_table), group=engine.group)
+        ops = engine._ops_factory(local_table)
+        if not hasattr(ops, "all_reduce_sum"):
+            ops.all_reduce_sum = lambda arr: engine.all_reduce(np.ascontiguousarray(arr, dtype=np.int64))      # the engine's control transport
+        self._sharded = ShardedTable(ops, group=engine.group, assets_share_a_rank=True)
 
     # -- routing -----------------------------------------------------------------------------------------
     def _mine(self, keys):
@@ -208,7 +211,11 @@ class ShardedHipTable:
         return self._sharded.doc_freq(q_words, q_nbytes, dup_limit)
 
     def get_freq(self, keys, dup_limit=1000):
-        """Document frequency of the code stored under each key (0 for absent keys): owner lookup, then the sharded collision count."""
+        """
+        Document frequency of the code stored under each key (0 for absent keys).  The owner's frequency COLUMN cannot answer
+        it: the other shards hold rows with the same code under other keys.  So the owner supplies the code (one all-reduce) and
+        every shard counts it on the device, batched (``doc_freq``: the counts add, see there).
+        """
         words, nb = self.get(keys)
         out = np.zeros(len(nb), dtype=np.uint32)
         present = np.nonzero(nb)[0]

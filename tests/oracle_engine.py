@@ -128,6 +128,10 @@ class OracleTable:
             out[q] = len(np.unique(assets))
         return out
 
+    def doc_freq_counted(self, q_words, q_nbytes=None, dup_limit=1000):
+        keys, _, _, cnt = self.search_within(q_words, q_nbytes, dup_limit, 0)
+        return self.doc_freq(q_words, q_nbytes, dup_limit), cnt.astype(np.uint32)
+
     def get_freq(self, keys, dup_limit=1000):
         words, nb = self.get(keys)
         out = np.zeros(len(nb), dtype=np.uint32)

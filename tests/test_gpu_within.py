@@ -163,6 +163,10 @@ def test_frequency_column_vs_model(hip_engine, nbytes, key_words):
             np.testing.assert_array_equal(got, want)
             sample = rng.integers(0, n, size=40)
             np.testing.assert_array_equal(t.doc_freq(words[sample], None, dup_limit), want[sample])
+            # the counted form: the same frequencies and, beside them, how many colliding rows each was taken over
+            freq, coll = t.doc_freq_counted(words[sample], None, dup_limit)
+            np.testing.assert_array_equal(freq, want[sample])
+            np.testing.assert_array_equal(coll, t.search_within(words[sample], None, dup_limit, 0)[3])
         assert hip_engine.stats()["freq_builds"] == builds + 2          # one build per dup_limit, reused by lookups
         t.get_freq(keys[:10], 7)
         assert hip_engine.stats()["freq_builds"] == builds + 2

@@ -36,6 +36,9 @@ class OracleShardOps:
         buf[rec_bytes : rec_bytes + nq * 4] = cnt.astype("<i4").view(np.uint8)
         return torch.from_numpy(buf)
 
+    def local_doc_freq(self, q_words, q_nbytes, dup_limit):
+        return self.table.doc_freq_counted(q_words, q_nbytes, dup_limit)
+
     def merge(self, gathered, n_lists, nq, k):
         rec_bytes, blk = block_bytes(nq, k)
         raw = gathered.numpy()

@@ -59,6 +59,10 @@ def scenario(manager, reopen=None):
     out.append(dump(idx.search_assets(queries[6], limit=10, exact=True)))                 # hard-boundary collision search
     table = idx._sp_tables["CONTENT_TEXT_V0"]
     out.append([int(f) for f in table.doc_freq([s[0], s[1], s[2], bytes(16)])])
+    # both branches of the sharded count: above, every collision fits the limit and the shards' counts add;
+    # with a limit of 3 the list is cut ACROSS the shards in key order and only the merged list knows which assets survive
+    out.append([int(f) for f in table.doc_freq([s[0], s[1], s[2], bytes(16)], dup_limit=3)])
+    out.append([int(f) for f in table.doc_freq([s[0], s[1]], dup_limit=1)])
     out.append(table.size)
     out.append(manager.get_asset("main", assets[3].iscc_id).iscc_code)
     if reopen is not None:
