@@ -471,7 +471,7 @@ struct Batch {
         // A self-tightening pass is decided once per job (use_mfma over the whole segment) and lives on the matrix cores: EVERY
         // stretch of it runs there, also a short last one -- the XOR + popcount kernels have no MODE_SELF
         if (use_mfma(rows) || mode == isk::MODE_SELF) {
-            const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad);
+            const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad, j.pack);
             const uint32_t chunks = (nq_pad + g * 32 - 1) / (g * 32);
             const uint64_t rps = isk::mfma_rows_per_wave_step((int)j.W, j.pack);
             const uint64_t steps = (rows + rps - 1) / rps;
@@ -567,7 +567,7 @@ struct Batch {
             auto collect_from = [&](uint64_t from, bool self = false) -> int {
                 uint64_t stretch = s.n;
                 // (the MFMA kernel reads the rows once per CHUNK of up to 1 024 / W queries: one chunk has nothing to share)
-                const bool shared = use_mfma(s.n - from) ? nq_pad > isk::mfma_groups_per_chunk((int)j.W, nq_pad) * 32 : groups > 1;
+                const bool shared = use_mfma(s.n - from) ? nq_pad > isk::mfma_groups_per_chunk((int)j.W, nq_pad, j.pack) * 32 : groups > 1;
                 // (matrix-core launches: the chunks' blocks are all resident and walk a stretch in step, so three times the size
                 //  still shares it in the caches and every launch saved is ~30 us of ramp and tail.  Same box, factor 1 / 2 / 3 / 4:
                 //  256-bit 9.31 / 8.90 / 8.79 / 8.72 ms, 128-bit 4.67 / 4.55 / 4.53 / 4.52, 192-bit 7.88 / 7.74 / 7.67 / 7.99)

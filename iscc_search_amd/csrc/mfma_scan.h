@@ -11,8 +11,8 @@ namespace isk {
 
 constexpr int MFMA_MAX_LDS = 48 * 1024;   // a chunk needs <= 40 KB of dynamic LDS: within the default limit, nothing to configure
 
-// query groups (32 queries each, an even number) one block keeps in LDS for W compared words
-uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad);
+// query groups (32 queries each; an even number unless `pack`) one block keeps in LDS for W compared words
+uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad, bool pack);
 size_t mfma_lds_bytes(int W, uint32_t groups);
 uint32_t mfma_waves_per_block();
 // pack: 64-bit codes on mfma_pack_kernel (two row tiles per accumulator, packed f16 fold); the batch must not hold an all-zero query

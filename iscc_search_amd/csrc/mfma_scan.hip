@@ -684,24 +684,32 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         load_rows(ns, x);                                 // the next step's rows, in flight during this one (same registers)
 
         // two B buffers and two accumulator sets: the fragment of group g + 2 is requested while group g + 1 multiplies
-        v4i by = lbl[0], bx = lbl[64];
-        uint32_t thrY = lt[0], thrX = lt[32];
+        // (any number of groups: pairs of stages while at least three groups remain, then one stage + the last fold for an even
+        //  rest or the last fold alone for an odd one -- 17..32 queries are ONE group, not one and a padding group)
+        v4i by = lbl[0], bx = lbl[groups > 1 ? 64 : 0];
+        uint32_t thrY = lt[0], thrX = lt[groups > 1 ? 32 : 0];
         Acc accY, accX;
         uint32_t mY, mX;
         first_group(accY, by);
+        uint32_t g = 0;
 #pragma unroll 1
-        for (uint32_t g = 0; g + 2 < groups; g += 2) {
+        for (; g + 2 < groups; g += 2) {
             by = lbl[(g + 2) * 64];                       // consumed by the stage before
             const uint32_t thrYn = lt[(g + 2) * 32];
             if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); __builtin_expect(mk != 0, 0)) save_hits(accY, mk, thrY, g, step);
             thrY = thrYn;
-            bx = lbl[(g + 3) * 64];
-            const uint32_t thrXn = lt[(g + 3) * 32];
+            const uint32_t g3 = g + 3 < groups ? g + 3 : g + 2;       // (an odd count has no group g + 3: nothing is multiplied with it)
+            bx = lbl[g3 * 64];
+            const uint32_t thrXn = lt[g3 * 32];
             if (const uint64_t mk = stage(accY, accX, by, thrX, mX); __builtin_expect(mk != 0, 0)) save_hits(accX, mk, thrX, g + 1, step);
             thrX = thrXn;
         }
-        if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); mk != 0) save_hits(accY, mk, thrY, groups - 2, step);
-        if (const uint64_t mk = last_fold(accX, thrX, mX); mk != 0) save_hits(accX, mk, thrX, groups - 1, step);
+        if (g + 1 < groups) {
+            if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
+            if (const uint64_t mk = last_fold(accX, thrX, mX); mk != 0) save_hits(accX, mk, thrX, g + 1, step);
+        } else {
+            if (const uint64_t mk = last_fold(accY, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
+        }
         // what the PREVIOUS step's appends returned (issued a whole step ago: no wait), then this step's blocks
         if constexpr (MODE == MODE_SELF) pend_complete();
         if (rcount) process_ring(step);
@@ -737,11 +745,12 @@ static int launch_w(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanP
     return 0;
 }
 
-uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad) {
+uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad, bool pack) {
     // LDS per group: 32 queries x (32 * W bytes of +1/-1 nibbles + thr + popc); at most 40 KB per block, four blocks per CU
     static const uint32_t max_groups[5] = {0, 32, 16, 10, 8};
     uint32_t need = (nq_pad + 31) / 32;
-    need += need & 1;                         // the pipeline walks the groups in pairs
+    if (pack) return need < 1 ? 1 : (need < max_groups[1] ? need : max_groups[1]);      // mfma_pack_kernel takes any number of groups
+    need += need & 1;                         // the pipeline of mfma_scan_kernel walks the groups in pairs
     if (need < 2) need = 2;
     return need < max_groups[W] ? need : max_groups[W];
 }
