@@ -394,6 +394,7 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 // d2 = +64 (query == 0 against a row of all ones) would carry into the exponent and halve the resolution of the low half:
 // the host routes a batch holding an all-zero 64-bit query to the kernel above (Batch::begin, isccsearch.hip).
 constexpr int PK_TILES = 4;                                             // row tiles per wave and step
+constexpr uint32_t PK_DEEP_GROUPS = 6;                                  // chunks of up to this many groups (192 queries) keep four steps of rows in flight
 constexpr uint32_t PK_RING_ENTRIES = 8, PK_RING_ENTRY_DWORDS = 36;      // per wave: saved accumulator blocks of lanes that hold a hit (144 B each)
 __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -408,7 +409,12 @@ __device__ __forceinline__ uint32_t live_packed(const float* addr) {
 #define ISK_MF1(n, av) "v_mfma_f32_32x32x64_f8f6f4 %[" #n "], %[" #av "], %[b], %[mg] cbsz:4 blgp:4\n"
 #define ISK_MF2(n, av) "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #n "], %[" #av "], %[b], %[" #n "], %[sh], %[so] op_sel_hi:[0,0,0] cbsz:4 blgp:4\n"
 
-template <int MODE>
+// DEPTH: steps whose rows a wave keeps in flight.  A chunk of 32 groups works ~5 000 cycles on a step's 1 KB of rows and one
+// step ahead hides any latency; a chunk of one or two groups is done in ~400, and with one step (3 waves x 4 SIMDs x 1 KB =
+// 12 KB per CU) in flight the scan crawled at 2.5 TB/s, bound by memory latency (32 queries: 0.33 ms per 100 M rows,
+// profiles/r03_step_timelines.txt).  Small chunks run the DEPTH = 4 instantiation: the step body four times per loop trip,
+// each on its own row registers.
+template <int MODE, int DEPTH>
 __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p, const uint32_t groups) {
     constexpr int MT = PK_TILES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -633,8 +639,9 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
             for (int t = 0; t < MT; ++t) dst[t] = col32[row_of(st, t) * 2 + h];
         }
     };
-    uint32_t x[MT];
-    load_rows(step, x);
+    uint32_t x[DEPTH][MT];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_rows(step + d * stride < nsteps ? step + d * stride : step, x[d]);
     const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     // thresholds [256 wave, 256 wave + 256) are this wave's to keep fresh, four per lane.  The lane number is RECOMPUTED at
     // each use (mbcnt of a laundered zero), or hipcc keeps a 64-bit global address and an LDS address alive through the
@@ -653,8 +660,8 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     const uint32_t slices = groups * 32 * 4 / 64, nwaves = gridDim.x * (MBLOCK / 64);
     const uint32_t gw = blockIdx.x * (MBLOCK / 64) + wave_s;
     uint32_t trip = 0;
-    for (; step < nsteps; step += stride, ++trip) {
-        const uint64_t ns = step + stride < nsteps ? step + stride : step;
+    auto one_step = [&](uint32_t (&x)[MT]) {
+        const uint64_t ns = step + DEPTH * stride < nsteps ? step + DEPTH * stride : step;
         uint32_t fresh[4] = {0u, 0u, 0u, 0u};
         const bool look = trip < 4 || (trip & refresh_mask) == 0;
         const bool refresh_now = refresh && look;
@@ -720,17 +727,32 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
             }
             if (refresh_now) *reinterpret_cast<uint4*>(lthr + fresh_index()) = make_uint4(fresh[0], fresh[1], fresh[2], fresh[3]);
         }
+    };
+    while (step < nsteps) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (step >= nsteps) break;
+            one_step(x[d]);
+            step += stride;
+            ++trip;
+        }
     }
     if constexpr (MODE == MODE_SELF) pend_complete();
+}
+
+template <int DEPTH>
+static void launch_pack_depth(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
+    if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_pack_kernel<MODE_COLLECT, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_pack_kernel<MODE_STRETCH, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_SELF) hipLaunchKernelGGL((mfma_pack_kernel<MODE_SELF, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else hipLaunchKernelGGL((mfma_pack_kernel<MODE_BOTH, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
 }
 
 static int launch_pack(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
     lds += MBLOCK / 64 * PK_RING_ENTRIES * PK_RING_ENTRY_DWORDS * sizeof(uint32_t);       // the waves' rings of saved accumulator blocks
     if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
-    if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_pack_kernel<MODE_COLLECT>), grid, dim3(MBLOCK), lds, st, p, groups);
-    else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_pack_kernel<MODE_STRETCH>), grid, dim3(MBLOCK), lds, st, p, groups);
-    else if (mode == MODE_SELF) hipLaunchKernelGGL((mfma_pack_kernel<MODE_SELF>), grid, dim3(MBLOCK), lds, st, p, groups);
-    else hipLaunchKernelGGL((mfma_pack_kernel<MODE_BOTH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    if (groups <= PK_DEEP_GROUPS) launch_pack_depth<4>(mode, grid, lds, st, p, groups);
+    else launch_pack_depth<1>(mode, grid, lds, st, p, groups);
     return 0;
 }
 
