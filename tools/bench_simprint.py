@@ -1,6 +1,19 @@
 #!/usr/bin/env python3
-"""End-to-end timing of HipSimprintIndex (config 5 shape): approximate search_raw (GPU search + host IDF scoring,
-document frequencies from the device), hard-boundary search_exact, and the frequency-column build."""
+"""
+BASELINE config 5 end to end at its stated size: 10 M chunk fingerprints per table (``usearch/index.py:1746-1763`` keeps one
+fixed-``ndim`` table per simprint type), 128-bit chunk-pointer keys, for ndim = 64 / 128 / 256:
+
+  * ``search_raw``  -- the approximate path of ``iscc_search/indexes/simprint/usearch_core.py:137-269`` on
+    ``HipSimprintIndex``: ONE batched exact Hamming search (count = limit x 20), stored vectors and document frequencies of the
+    matches from the device, IDF-weighted scoring on the host;
+  * ``search_exact`` -- the hard-boundary collision search (``lmdb_ops.py:169-301``): range-limited lookups at distance 0.
+
+Every time is split into the DEVICE share (wall time inside the C-ABI calls: search, vector gather, frequency column) and the
+HOST share (everything else: query packing, match filtering, per-asset aggregation, scoring, object construction).
+
+usage (GPU box): python tools/bench_simprint.py [chunks per table, default 10000000] [ndim ...]
+   run under `rocprofv3 --kernel-trace --stats` for the per-kernel table committed as profiles/r03_kernel_stats_simprint.csv
+"""
 import os
 import sys
 import time
@@ -10,42 +23,91 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from iscc_search_amd.engine import HipEngine  # noqa: E402
-from iscc_search_amd.simprint import HipSimprintIndex, pack_chunk_pointer  # noqa: E402
+from iscc_search_amd.simprint import HipSimprintIndex  # noqa: E402
 
-eng = HipEngine(0)
-for _item in filter(None, os.environ.get("ISCC_HIP_OPTS", "").split(",")):      # e.g. ISCC_HIP_OPTS=mfma=0
-    eng.set_option(_item.split("=")[0].strip(), int(_item.split("=")[1]))
-rng = np.random.default_rng(0)
-n_assets, chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000, 40      # 4 M chunks
-ndim = 128
-idx = HipSimprintIndex(eng, ndim=ndim)
-t0 = time.perf_counter()
-bodies = (np.arange(n_assets, dtype=np.uint64) + np.uint64(1)).astype(">u8").view("V8")
-for a0 in range(0, n_assets, 10_000):
-    a1 = min(n_assets, a0 + 10_000)
-    vecs = rng.integers(0, 256, size=((a1 - a0) * chunks, ndim // 8), dtype=np.uint8)
-    keys = [pack_chunk_pointer(bytes(bodies[a]), c * 100, 100) for a in range(a0, a1) for c in range(chunks)]
-    idx.add_raw(keys, list(vecs))
-    if a0 == 0:
-        first = vecs[: chunks * 5].copy()
-print(f"ingest {idx.size} chunks: {time.perf_counter() - t0:.1f} s")
-for nq in (16, 64, 256):
-    # query = chunks of the first assets with a few bits flipped
-    q = first[:nq].copy()
-    q[:, 0] ^= 3
-    simprints = [bytes(r) for r in q]
-    for limit in (10,):
-        for mode, kw in (("callback freq=1", dict(doc_freq_fn=lambda s: 1)), ("device doc freq", dict(device_doc_freq=True)), ("device doc freq", dict(device_doc_freq=True))):
-            b0 = eng.stats()["freq_builds"]
+CHUNKS_PER_ASSET = 40
+
+
+class DeviceClock:
+    """Wall time spent inside the index's device entry points (each ends with the results on the host)."""
+
+    NAMES = ("search_arrays", "search_within", "get_many", "get_freq", "doc_freq")
+
+    def __init__(self, index):
+        self.seconds = 0.0
+        for name in self.NAMES:
+            inner = getattr(index, name)
+
+            def timed(*a, _inner=inner, **kw):
+                t0 = time.perf_counter()
+                try:
+                    return _inner(*a, **kw)
+                finally:
+                    self.seconds += time.perf_counter() - t0
+
+            setattr(index, name, timed)
+
+    def take(self):
+        s, self.seconds = self.seconds, 0.0
+        return s
+
+
+def build(eng, ndim, n_chunks, rng):
+    idx = HipSimprintIndex(eng, ndim=ndim)
+    nb = ndim // 8
+    first = None
+    t0 = time.perf_counter()
+    for lo in range(0, n_chunks, 1 << 20):
+        n = min(1 << 20, n_chunks - lo)
+        rows = np.arange(lo, lo + n, dtype=np.uint64)
+        keys = np.stack([rows // np.uint64(CHUNKS_PER_ASSET) + np.uint64(1),                          # asset body (big-endian value)
+                         ((rows % np.uint64(CHUNKS_PER_ASSET)) * np.uint64(100) << np.uint64(32)) | np.uint64(100)], axis=1)   # offset | size
+        vecs = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+        idx._index.add(keys, vecs, trusted_unique=True)
+        if first is None:
+            first = vecs[: CHUNKS_PER_ASSET * 16].copy()
+    return idx, first, time.perf_counter() - t0
+
+
+def main():
+    n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+    ndims = [int(a) for a in sys.argv[2:]] or [64, 128, 256]
+    eng = HipEngine(0)
+    for item in filter(None, os.environ.get("ISCC_HIP_OPTS", "").split(",")):      # e.g. ISCC_HIP_OPTS=mfma=0
+        eng.set_option(item.split("=")[0].strip(), int(item.split("=")[1]))
+    rng = np.random.default_rng(0)
+    n_assets = n_chunks // CHUNKS_PER_ASSET
+    for ndim in ndims:
+        idx, first, secs = build(eng, ndim, n_chunks, rng)
+        print(f"== ndim {ndim}: {idx.size} chunks of {n_assets} assets ingested in {secs:.1f} s")
+        clock = DeviceClock(idx._index)
+        for nq in (16, 64, 256, 512):
+            q = first[:nq].copy()
+            q[:, 0] ^= 3                                     # two flipped bits: an approximate, not an exact, match
+            simprints = [bytes(r) for r in q]
+            kw = dict(limit=20, threshold=0.75, detailed=True, total_assets=n_assets, device_doc_freq=True)
+            idx.search_raw(simprints, **kw)                  # first call: frequency column, pinned buffers
+            clock.take()
+            reps = 5
             t0 = time.perf_counter()
-            res = idx.search_raw(simprints, limit=limit * 2, threshold=0.75, detailed=True, total_assets=n_assets, **kw)
-            dt = time.perf_counter() - t0
-            built = eng.stats()["freq_builds"] - b0
-            print(f"search_raw nq={nq} limit={limit*2} (count={limit*2*20}) {mode}{' [column built]' if built else ''}: "
-                  f"{dt*1e3:8.2f} ms, {len(res)} assets, top score {res[0].score:.4f}")
-        exact_q = [bytes(r) for r in first[:nq]]
-        idx.search_exact(exact_q, limit=limit * 2, threshold=0.0, detailed=True)     # first call grows the pinned result buffers
-        t0 = time.perf_counter()
-        res = idx.search_exact(exact_q, limit=limit * 2, threshold=0.0, detailed=True)
-        print(f"search_exact nq={nq}: {(time.perf_counter() - t0)*1e3:8.2f} ms, {len(res)} assets")
-eng.close()
+            for _ in range(reps):
+                res = idx.search_raw(simprints, **kw)
+            total = (time.perf_counter() - t0) / reps
+            dev = clock.take() / reps
+            print(f"search_raw   nq={nq:3d} count=400: {total * 1e3:7.2f} ms = device {dev * 1e3:6.2f} + host {(total - dev) * 1e3:6.2f}; "
+                  f"{len(res)} assets, top score {res[0].score:.4f}")
+            exact_q = [bytes(r) for r in first[:nq]]
+            idx.search_exact(exact_q, limit=20, threshold=0.0, detailed=True)
+            clock.take()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = idx.search_exact(exact_q, limit=20, threshold=0.0, detailed=True)
+            total = (time.perf_counter() - t0) / reps
+            dev = clock.take() / reps
+            print(f"search_exact nq={nq:3d}          : {total * 1e3:7.2f} ms = device {dev * 1e3:6.2f} + host {(total - dev) * 1e3:6.2f}; {len(res)} assets")
+        idx.close()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
