@@ -52,6 +52,9 @@ typedef const __attribute__((address_space(3))) float* lds_thr_ptr;
 #define ISK_MFMA_TILES_W4 2
 #endif
 template <int W> constexpr int mfma_tiles() { return W == 4 ? ISK_MFMA_TILES_W4 : 2; }
+#ifndef ISK_ORDERED_STAGE
+#define ISK_ORDERED_STAGE 1           // experiment switch: 0 = the builtin-scheduled stage of round 2 for codes of two to four words
+#endif
 #ifndef ISK_SCALAR_STEPS_FROM_W
 #define ISK_SCALAR_STEPS_FROM_W 2     // experiment switch: code widths (in 64-bit words) from which the step number is kept scalar
 #endif
@@ -112,6 +115,35 @@ struct Pending {
         meta = 0;
     }
 };
+
+// ---- the stage of mfma_scan_kernel for codes of two to four words, in ISSUE ORDER (round 3) ---------------------------------
+// hipcc issued the 2 W MFMAs of a group back to back and the 17-instruction fold of the previous group behind them; the two
+// or three waves of a SIMD then tend to fold at the same time and the matrix pipe idles (0.69 busy at W = 4, 100 M x 256-bit).
+// As in mfma_pack_kernel below, the MFMAs and the fold are single-instruction asm statements in the order they should issue:
+// MFMA (tile 0, word 0), MFMA (tile 1, word 0), then after every further MFMA a few fold instructions of the PREVIOUS group.
+// hipcc places no hazard nops for asm: the fold starts after the stage's second MFMA and walks accumulator 0 of the old group
+// first, so every read of an MFMA result lies >= 12 instructions behind that MFMA (checked by tools/audit_kernels.py).
+template <int N>
+__device__ __forceinline__ void fold_op(float& mA, float& mB, const v16f& o0, const v16f& o1) {
+    if constexpr (N == 0) asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(mA) : "v"(o0[0]), "v"(o0[1]), "v"(o0[2]));
+    else if constexpr (N <= 6) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(mA) : "v"(o0[2 * N + 1]), "v"(o0[2 * N + 2]));
+    else if constexpr (N == 7) asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(mB) : "v"(o1[0]), "v"(o1[1]), "v"(o1[2]));
+    else if constexpr (N <= 13) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(mB) : "v"(o1[2 * (N - 7) + 1]), "v"(o1[2 * (N - 7) + 2]));
+    else if constexpr (N == 14) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(mA) : "v"(o0[15]), "v"(o1[15]));
+    else asm volatile("v_min_f32 %0, %0, %1" : "+v"(mA) : "v"(mB));
+}
+template <int FROM, int TO>
+__device__ __forceinline__ void fold_ops(float& mA, float& mB, const v16f& o0, const v16f& o1) {
+    if constexpr (FROM < TO && FROM < 16) {
+        fold_op<FROM>(mA, mB, o0, o1);
+        fold_ops<FROM + 1, TO>(mA, mB, o0, o1);
+    }
+}
+template <bool FIRST_WORD>
+__device__ __forceinline__ void mfma_asm(v16f& acc, const v4i& a, const v4i& b) {
+    if constexpr (FIRST_WORD) asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, 0 cbsz:4 blgp:4" : "=&v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+v"(acc) : "v"(a), "v"(b));
+}
 
 // LDS image of a chunk: B fragments [groups][W][64] v4i | thr[groups * 32] (float) | popc[groups * 32]
 template <int W, int MODE>
@@ -176,20 +208,12 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 #pragma unroll
     for (int w = 0; w < W; ++w) col32[w] = reinterpret_cast<const uint32_t*>(p.col[w]);
 
+    constexpr bool ORDERED = W >= 2 && MT == 2 && ISK_ORDERED_STAGE;      // the stage in issue order (inline asm), see fold_op above
     constexpr bool ASYNC = W <= 2;       // five more live registers: W = 3 would spill, W = 4 is at two waves per SIMD already
     Pending pend;
     // a lane's 16 results per tile all belong to query g * 32 + (lane & 31): fold both tiles (two chains), compare once
-    auto reduce = [&](const Acc& acc, float thr, uint32_t g, uint64_t st) {
-        float m[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) m[t] = min3f(acc.t[t][0], acc.t[t][1], acc.t[t][2]);
-#pragma unroll
-        for (int i = 3; i < 15; i += 2)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) m[t] = min3f(m[t], acc.t[t][i], acc.t[t][i + 1]);
-        float mall;
-        if constexpr (MT == 2) mall = fminf(min3f(m[0], acc.t[0][15], acc.t[1][15]), m[1]);
-        else mall = fminf(m[0], acc.t[0][15]);
+    // the rare path: some result of the lane is within its query's threshold
+    auto rare = [&](const Acc& acc, float thr, uint32_t g, uint64_t st, float mall) {
         if (__builtin_expect(mall <= thr, 0)) {
             // rare: result `reg` of tile t is row (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) of that tile.
             // The step number is laundered so that hipcc does not hoist 32 row numbers per lane out of the group loop
@@ -230,6 +254,19 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
                 }
             }
         }
+    };
+    auto reduce = [&](const Acc& acc, float thr, uint32_t g, uint64_t st) {
+        float m[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) m[t] = min3f(acc.t[t][0], acc.t[t][1], acc.t[t][2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) m[t] = min3f(m[t], acc.t[t][i], acc.t[t][i + 1]);
+        float mall;
+        if constexpr (MT == 2) mall = fminf(min3f(m[0], acc.t[0][15], acc.t[1][15]), m[1]);
+        else mall = fminf(m[0], acc.t[0][15]);
+        rare(acc, thr, g, st, mall);
     };
 
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -298,6 +335,82 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
                 a[t][w] = v8i{(int)(nibbles(x[t][w], 0) << 1), (int)(nibbles(x[t][w], 1) << 1), (int)(nibbles(x[t][w], 2) << 1),
                               (int)(nibbles(x[t][w], 3) << 1), 0, 0, 0, 0};                      // bit ? 1.0 (0x2) : 0
 
+        if constexpr (ORDERED) {
+            // ---- two to four words: the stage in issue order (fold_op / mfma_asm above) --------------------------------
+            // One B buffer PER WORD and group parity (2 W fragments in registers): the fragments of group g + 2 are requested
+            // while group g + 1 multiplies.
+            v4i a4[MT][W];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int w = 0; w < W; ++w) a4[t][w] = v4i{a[t][w][0], a[t][w][1], a[t][w][2], a[t][w][3]};
+            v4i bX[W], bY[W];
+            auto fetch = [&](v4i (&dst)[W], uint32_t g) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) dst[w] = lbl[((size_t)g * W + w) * 64];
+            };
+            // MFMAs of group `nw` (tile 0 and 1 of word 0 first), the fold of group `od` spread behind every further MFMA;
+            // returns the lanes with a result within the threshold as a wave mask and the lane's minimum in `m`
+            constexpr int GAPS = 2 * W - 1, PER = (16 + GAPS - 1) / GAPS;
+            auto stage = [&](Acc& nw, const Acc& od, const v4i (&b)[W], float thr, float& m) -> uint64_t {
+                float mA, mB;
+                mfma_asm<true>(nw.t[0], a4[0][0], b[0]);
+                mfma_asm<true>(nw.t[1], a4[1][0], b[0]);
+                fold_ops<0, PER>(mA, mB, od.t[0], od.t[1]);
+                if constexpr (W >= 2) { mfma_asm<false>(nw.t[0], a4[0][1], b[1]); fold_ops<PER, 2 * PER>(mA, mB, od.t[0], od.t[1]);
+                                        mfma_asm<false>(nw.t[1], a4[1][1], b[1]); fold_ops<2 * PER, 3 * PER>(mA, mB, od.t[0], od.t[1]); }
+                if constexpr (W >= 3) { mfma_asm<false>(nw.t[0], a4[0][2], b[2]); fold_ops<3 * PER, 4 * PER>(mA, mB, od.t[0], od.t[1]);
+                                        mfma_asm<false>(nw.t[1], a4[1][2], b[2]); fold_ops<4 * PER, 5 * PER>(mA, mB, od.t[0], od.t[1]); }
+                if constexpr (W >= 4) { mfma_asm<false>(nw.t[0], a4[0][3], b[3]); fold_ops<5 * PER, 6 * PER>(mA, mB, od.t[0], od.t[1]);
+                                        mfma_asm<false>(nw.t[1], a4[1][3], b[3]); fold_ops<6 * PER, 7 * PER>(mA, mB, od.t[0], od.t[1]); }
+                uint64_t mask;
+                asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(mask) : "v"(mA), "v"(thr));
+                m = mA;
+                return mask;
+            };
+            auto only_mfmas = [&](Acc& nw, const v4i (&b)[W]) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (w == 0) { mfma_asm<true>(nw.t[0], a4[0][0], b[0]); mfma_asm<true>(nw.t[1], a4[1][0], b[0]); }
+                    else { mfma_asm<false>(nw.t[0], a4[0][w], b[w]); mfma_asm<false>(nw.t[1], a4[1][w], b[w]); }
+                }
+                asm volatile("s_nop 7\ns_nop 3" : "+v"(nw.t[0]), "+v"(nw.t[1]));      // results readable by what follows
+            };
+            auto only_fold = [&](const Acc& od, float thr, float& m) -> uint64_t {
+                float mA, mB;
+                asm volatile("s_nop 7\ns_nop 3");
+                fold_ops<0, 16>(mA, mB, od.t[0], od.t[1]);
+                uint64_t mask;
+                asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(mask) : "v"(mA), "v"(thr));
+                m = mA;
+                return mask;
+            };
+            Acc accX, accY;
+            float thrX, thrY = lt[0], mX, mY;
+            fetch(bY, 0);
+            fetch(bX, 1);                                   // groups >= 2 (mfma_groups_per_chunk)
+            thrX = lt[32];
+            only_mfmas(accY, bY);
+            uint32_t g = 0;
+#pragma unroll 1
+            for (; g + 2 < groups; g += 2) {
+                fetch(bY, g + 2);
+                const float thrYn = lt[(g + 2) * 32];
+                if (const uint64_t mk = stage(accX, accY, bX, thrY, mY); __builtin_expect(mk != 0, 0)) rare(accY, thrY, g, step, mY);
+                thrY = thrYn;
+                const uint32_t g3 = g + 3 < groups ? g + 3 : g + 2;
+                fetch(bX, g3);
+                const float thrXn = lt[g3 * 32];
+                if (const uint64_t mk = stage(accY, accX, bY, thrX, mX); __builtin_expect(mk != 0, 0)) rare(accX, thrX, g + 1, step, mX);
+                thrX = thrXn;
+            }
+            if (g + 1 < groups) {
+                if (const uint64_t mk = stage(accX, accY, bX, thrY, mY); mk != 0) rare(accY, thrY, g, step, mY);
+                if (const uint64_t mk = only_fold(accX, thrX, mX); mk != 0) rare(accX, thrX, g + 1, step, mX);
+            } else {
+                if (const uint64_t mk = only_fold(accY, thrY, mY); mk != 0) rare(accY, thrY, g, step, mY);
+            }
+        } else {
         // Software pipeline over the (group, word) sequence: two B buffers (one word each) and two accumulator sets.
         // The fragment of the NEXT word is requested right after the MFMAs of the current one are issued (its buffer
         // was consumed one stage earlier), and the results of group g are folded while the MFMAs of group g + 1 run.
@@ -351,6 +464,7 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
             }
             reduce(accX, thrX, g, step);
         }
+        }       // (!ORDERED)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
