@@ -58,6 +58,7 @@ template <int W> constexpr int mfma_tiles() { return W == 4 ? ISK_MFMA_TILES_W4 
 #ifndef ISK_SCALAR_STEPS_FROM_W
 #define ISK_SCALAR_STEPS_FROM_W 2     // experiment switch: code widths (in 64-bit words) from which the step number is kept scalar
 #endif
+constexpr uint32_t PK_RING_ENTRIES = 8, PK_RING_ENTRY_DWORDS = 36;      // per wave: saved result blocks of lanes that hold a hit (144 B each)
 constexpr int MBLOCK = 256;           // 4 waves; a chunk's LDS image is <= 40 KB, so LDS admits four blocks per CU
 // Registers decide: the rare emit path (both accumulator sets live + 64-bit row numbers) peaks at 130-175 VGPRs, i.e. three
 // waves per SIMD for W <= 3 and two for W = 4.  Forcing four (128 VGPRs) spilled to scratch; the prototype measured
@@ -79,42 +80,6 @@ __device__ __forceinline__ float live_threshold(const float* addr) {
 // Dword j (0..3) of a 32-bit half: nibble t holds bit j + 4 t.  Rows (A) and queries (B) use the same map, so the k order
 // inside the instruction does not matter; lanes 0..31 carry the low half of a word and lanes 32..63 the high half on both sides.
 __device__ __forceinline__ uint32_t nibbles(uint32_t x, int j) { return (x >> j) & 0x11111111u; }
-
-// MODE_SELF: a candidate whose two atomics (list slot, distance counter) are IN FLIGHT.  Waiting for them on the spot costs
-// the wave ~1 us per candidate (~180 candidates per query over 100 M rows: 0.1 ms of a 3 ms pass); instead the results are
-// consumed at the lane's next candidate or at the end of the step, whichever comes first, when they have long arrived.
-struct Pending {
-    uint32_t slot, before;    // results of the atomics (valid once `meta` says so)
-    uint32_t lo, hi;          // the candidate word (hamming << 48) | row
-    uint32_t meta = 0;        // bit 31: pending; bit 30: `before` counts (hamming < tau_seen); bits 16..24: tau_seen; bits 0..9: query in chunk
-
-    __device__ __forceinline__ void issue(const ScanParams& p, uint32_t q0, uint32_t ql, int h, uint64_t row, int tau_seen) {
-        const uint32_t qi = q0 + ql;
-        const bool counted = h < tau_seen;
-        slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
-        if (counted) before = atomicAdd(&p.ghist[(uint64_t)qi * HB + (uint32_t)h], 1u);
-        lo = (uint32_t)row;
-        hi = ((uint32_t)h << 16) | (uint32_t)(row >> 32);
-        meta = 0x80000000u | (counted ? 0x40000000u : 0u) | ((uint32_t)tau_seen << 16) | ql;
-    }
-    template <bool PACKED = false>
-    __device__ __forceinline__ void complete(const ScanParams& p, uint32_t q0, const int* lpop) {
-        if (!(meta & 0x80000000u)) return;
-        const uint32_t ql = meta & 0x3FFu, qi = q0 + ql;
-        if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)hi << 32) | lo;
-        if (meta & 0x40000000u) {
-            const int tau_seen = (int)((meta >> 16) & 0x1FFu);
-            uint32_t* const counts = p.ghist + (uint64_t)qi * HB;
-            uint32_t b = before;
-            for (int t = (int)(hi >> 16);;) {       // as emit_self: count under every t < tau_seen until one proves k rows
-                if (b + 1 >= p.k) { lower_live<PACKED>(p, qi, t - lpop[ql]); break; }
-                if (++t >= tau_seen) break;
-                b = atomicAdd(&counts[(uint32_t)t], 1u);
-            }
-        }
-        meta = 0;
-    }
-};
 
 // ---- the stage of mfma_scan_kernel for codes of two to four words, in ISSUE ORDER (round 3) ---------------------------------
 // hipcc issued the 2 W MFMAs of a group back to back and the 17-instruction fold of the previous group behind them; the two
@@ -209,51 +174,79 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     for (int w = 0; w < W; ++w) col32[w] = reinterpret_cast<const uint32_t*>(p.col[w]);
 
     constexpr bool ORDERED = W >= 2 && MT == 2 && ISK_ORDERED_STAGE;      // the stage in issue order (inline asm), see fold_op above
-    constexpr bool ASYNC = W <= 2;       // five more live registers: W = 3 would spill, W = 4 is at two waves per SIMD already
-    Pending pend;
-    // a lane's 16 results per tile all belong to query g * 32 + (lane & 31): fold both tiles (two chains), compare once
-    // the rare path: some result of the lane is within its query's threshold
-    auto rare = [&](const Acc& acc, float thr, uint32_t g, uint64_t st, float mall) {
-        if (__builtin_expect(mall <= thr, 0)) {
-            // rare: result `reg` of tile t is row (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) of that tile.
-            // The step number is laundered so that hipcc does not hoist 32 row numbers per lane out of the group loop
-            // (that cost 64 VGPRs in the hot loop for a path taken once in ~10^3 group-steps).
-            uint32_t st_lo = (uint32_t)st, st_hi = (uint32_t)(st >> 32);
-            asm volatile("" : "+v"(st_lo), "+v"(st_hi));
-            const uint64_t base = (((uint64_t)st_hi << 32) | st_lo) * (32 * MT) + 4 * h;
-            const uint32_t ql = g * 32 + r;
-            const int pc = lpop[ql];
-            int tau_seen = (int)thr + pc;               // MODE_SELF: the threshold this compare ran under (>= the live one)
-            // MODE_SELF: the FIRST hit of the entry (nearly always the only one) is appended asynchronously -- see Pending
-            uint32_t hits = 0, first_off = 0;
-            float first_dot = 0.f;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if (acc.t[t][reg] <= thr) {
-                        const uint32_t off = (uint32_t)(t * 32 + (reg & 3) + 8 * (reg >> 2));
-                        const uint64_t row = base + off;
-                        if (row <= last_row) {
-                            if constexpr (MODE == MODE_SELF && !ASYNC) {
-                                tau_seen = emit_self(p, q0 + ql, (int)acc.t[t][reg] + pc, row, tau_seen, pc);
-                            } else if constexpr (MODE == MODE_SELF) {
-                                if (hits == 0) { first_dot = acc.t[t][reg]; first_off = off; }
-                                else tau_seen = emit_self(p, q0 + ql, (int)acc.t[t][reg] + pc, row, tau_seen, pc);
-                                hits += 1;
-                            } else {
-                                emit<MODE>(p, q0 + ql, (uint32_t)((int)acc.t[t][reg] + pc), row);
-                            }
-                        }
+    static_assert(MT == 2, "the candidate ring holds the two tiles' 32 results of a lane");
+    // ---- candidates: as in mfma_pack_kernel (below) -- the lanes that hold a result within their query's threshold copy their
+    // 32 results (+ query, threshold) into their wave's LDS ring and the stage loop goes on; at the end of the step the ring is
+    // walked with a real loop, TWO saved blocks per trip, lane v on result v & 31 of block v >> 5.  MODE_SELF: the list slot is
+    // consumed at the lane's next candidate or at the end of the next step, the distance counts are no-return atomics, and
+    // CHECKER lanes notice "k rows within t" (one counter read per look) and lower the live threshold.  (Round 2: 32 unrolled
+    // compares and two returned atomics + a dependent chain per candidate inside the stage loop: config 5's table -- 10 M x
+    // 128-bit, 512 queries, k = 400 -- scanned at 0.94 ms against 0.22 ms of matrix-pipe time.)
+    constexpr uint32_t RING_E = PK_RING_ENTRIES, ENTRY = PK_RING_ENTRY_DWORDS;
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(lpop + groups * 32) + wave * (RING_E * ENTRY);
+    uint32_t rcount = 0;
+    uint32_t pend_slot = 0, pend_lo = 0, pend_hi = 0x80000000u;        // pend_hi bit 31: nothing pending
+    auto pend_complete = [&]() {
+        if (!(pend_hi & 0x80000000u)) {
+            const uint32_t qi = q0 + (pend_hi >> 21);                   // query in chunk : 10 | hamming : 9 | row >> 32 : 12
+            if (pend_slot < p.cap) p.cand[(uint64_t)qi * p.cap + pend_slot] = ((uint64_t)((pend_hi >> 12) & 0x1FFu) << 48) | ((uint64_t)(pend_hi & 0xFFFu) << 32) | pend_lo;
+            pend_hi = 0x80000000u;
+        }
+    };
+    auto process_ring = [&](uint64_t st) {
+        const uint32_t sub = lane >> 5, ri = lane & 31;
+        const uint32_t off0 = (ri >> 4) * 32 + (ri & 3) + 8 * ((ri & 15) >> 2);
+        for (uint32_t e = 0; e < rcount; e += 2) {
+            if (e + sub < rcount) {
+                const uint32_t* const blk = ring + (e + sub) * ENTRY;
+                const float v = __uint_as_float(blk[ri]), thr = __uint_as_float(blk[33]);
+                const uint32_t head = blk[32], ql = head & 0xFFFFu;
+                const uint64_t row = st * (32 * MT) + off0 + 4 * (head >> 16);
+                if (v <= thr && row <= last_row) {
+                    const int pc = lpop[ql];
+                    const uint32_t hd = (uint32_t)((int)v + pc);
+                    if constexpr (MODE == MODE_SELF) {
+                        pend_complete();
+                        const uint32_t qi = q0 + ql;
+                        const int tau_seen = (int)thr + pc;
+                        pend_slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
+                        uint32_t* const counts = p.ghist + (uint64_t)qi * HB;
+                        for (int t = (int)hd; t < tau_seen; ++t) __hip_atomic_fetch_add(&counts[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pend_lo = (uint32_t)row;
+                        pend_hi = (ql << 21) | (hd << 12) | (uint32_t)(row >> 32);       // rows < 2^44
+                    } else {
+                        emit<MODE>(p, q0 + ql, hd, row);
                     }
-                }
-            if constexpr (MODE == MODE_SELF && ASYNC) {
-                if (hits) {
-                    pend.complete(p, q0, lpop);
-                    pend.issue(p, q0, ql, (int)first_dot + pc, base + first_off, tau_seen);
                 }
             }
         }
+        rcount = 0;
+    };
+    // `mask`: the lanes whose minimum is within their threshold (query g * 32 + (lane & 31), rows 4 * (lane >> 5) + ... of the tiles)
+    auto save_hits = [&](const Acc& acc, uint64_t mask, float thr, uint32_t g, uint64_t st) {
+        while (mask) {                              // wave-uniform; more than one trip only when the ring fills up
+            const uint32_t room = RING_E - rcount;
+            if (room == 0) { process_ring(st); continue; }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const bool mine = ((mask >> lane) & 1) != 0 && rank < room;
+            if (mine) {
+                uint32_t* const blk = ring + (rcount + rank) * ENTRY;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4)
+                        *reinterpret_cast<float4*>(blk + 16 * j + i) = make_float4(acc.t[j][i], acc.t[j][i + 1], acc.t[j][i + 2], acc.t[j][i + 3]);
+                *reinterpret_cast<uint2*>(blk + 32) = make_uint2((g * 32 + r) | (h << 16), __float_as_uint(thr));
+            }
+            const uint64_t taken = __builtin_amdgcn_ballot_w64(mine);
+            rcount += (uint32_t)__builtin_popcountll(taken);
+            mask &= ~taken;
+        }
+    };
+    // (the stage of 64-bit codes that stay off the packed kernel: fold by builtins, then the same ring)
+    auto rare = [&](const Acc& acc, float thr, uint32_t g, uint64_t st, float mall) {
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(mall <= thr);
+        if (__builtin_expect(mask != 0, 0)) save_hits(acc, mask, thr, g, st);
     };
     auto reduce = [&](const Acc& acc, float thr, uint32_t g, uint64_t st) {
         float m[MT];
@@ -309,8 +302,15 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
     load_rows(step, x);
     // MODE_SELF: wave w keeps the block's copy of thresholds [256 w, 256 w + 256) fresh -- requested here, written to LDS
     // after the group loop, picked up by all four waves from their next step on (a stale threshold is only a looser one)
-    const uint32_t fresh_at = wave * 256 + lane * 4;
-    const bool refresh = MODE == MODE_SELF && fresh_at < groups * 32 && q0 + fresh_at < p.nq_pad;   // nq_pad is a multiple of 8
+    // (the lane's slice of the thresholds is RECOMPUTED at each use -- mbcnt of a laundered zero -- or hipcc keeps a 64-bit global
+    //  address and an LDS address alive through the group loop: registers the 192-bit kernel does not have)
+    const uint32_t wave_sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    auto fresh_index = [&]() {
+        uint32_t z = 0;
+        asm volatile("" : "+v"(z));
+        return wave_sc * 256 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) * 4;
+    };
+    const bool refresh = MODE == MODE_SELF && wave * 256 + lane * 4 < groups * 32 && q0 + wave * 256 + lane * 4 < p.nq_pad;   // nq_pad is a multiple of 8
     // ... every `refresh_steps` steps when the chunk is full (32 groups), proportionally less often for smaller chunks
     const uint32_t refresh_mask = (groups >= 32 ? 1u : groups >= 16 ? 2u : groups >= 8 ? 4u : groups >= 4 ? 8u : 16u) * p.refresh_steps - 1u;
     uint32_t trip = 0;
@@ -321,10 +321,25 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
         //  arrives every row within it is appended -- a 4 M-row table would be scanned whole under it at 16 steps per look)
         const bool look = trip < 8 || (trip & refresh_mask) == 0;
         const bool refresh_now = refresh && look;                             // (MODE_SELF only: `refresh` is false otherwise)
+        uint32_t chk_count = 0, chk_what = ~0u;       // chk_what: query in chunk | hamming level << 16, ~0: no task
         if constexpr (MODE == MODE_SELF) {
             if (refresh_now) {
+                const float* const src = p.thr_live + q0 + fresh_index();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fresh[i] = live_threshold(p.thr_live + q0 + fresh_at + i);
+                for (int i = 0; i < 4; ++i) fresh[i] = live_threshold(src + i);
+            }
+            // checkers: task (query, j) reads count[q][tau_q - j], j = 1..4 (see mfma_pack_kernel)
+            const uint32_t slices = groups * 32 * 4 / 64, nwaves = gridDim.x * (MBLOCK / 64);
+            const uint32_t gw = blockIdx.x * (MBLOCK / 64) + wave_sc;
+            const uint32_t slice = nwaves >= slices ? gw : (gw + trip * nwaves) % slices;
+            if (look && slice < slices) {
+                const uint32_t task = slice * 64 + lane, ql = task >> 2;
+                const float thr = lthr[ql];
+                const int level = (int)thr + lpop[ql] - 1 - (int)(task & 3);
+                if (thr > -1.0e8f && level >= 0 && q0 + ql < p.nq_pad) {
+                    chk_what = ql | ((uint32_t)level << 16);
+                    chk_count = (uint32_t)__hip_atomic_load(reinterpret_cast<const int*>(p.ghist + (uint64_t)(q0 + ql) * HB + level), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         load_rows(ns, xn);                                                          // next step's rows, in flight during this one
@@ -396,19 +411,19 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
             for (; g + 2 < groups; g += 2) {
                 fetch(bY, g + 2);
                 const float thrYn = lt[(g + 2) * 32];
-                if (const uint64_t mk = stage(accX, accY, bX, thrY, mY); __builtin_expect(mk != 0, 0)) rare(accY, thrY, g, step, mY);
+                if (const uint64_t mk = stage(accX, accY, bX, thrY, mY); __builtin_expect(mk != 0, 0)) save_hits(accY, mk, thrY, g, step);
                 thrY = thrYn;
                 const uint32_t g3 = g + 3 < groups ? g + 3 : g + 2;
                 fetch(bX, g3);
                 const float thrXn = lt[g3 * 32];
-                if (const uint64_t mk = stage(accY, accX, bY, thrX, mX); __builtin_expect(mk != 0, 0)) rare(accX, thrX, g + 1, step, mX);
+                if (const uint64_t mk = stage(accY, accX, bY, thrX, mX); __builtin_expect(mk != 0, 0)) save_hits(accX, mk, thrX, g + 1, step);
                 thrX = thrXn;
             }
             if (g + 1 < groups) {
-                if (const uint64_t mk = stage(accX, accY, bX, thrY, mY); mk != 0) rare(accY, thrY, g, step, mY);
-                if (const uint64_t mk = only_fold(accX, thrX, mX); mk != 0) rare(accX, thrX, g + 1, step, mX);
+                if (const uint64_t mk = stage(accX, accY, bX, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
+                if (const uint64_t mk = only_fold(accX, thrX, mX); mk != 0) save_hits(accX, mk, thrX, g + 1, step);
             } else {
-                if (const uint64_t mk = only_fold(accY, thrY, mY); mk != 0) rare(accY, thrY, g, step, mY);
+                if (const uint64_t mk = only_fold(accY, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
             }
         } else {
         // Software pipeline over the (group, word) sequence: two B buffers (one word each) and two accumulator sets.
@@ -469,14 +484,18 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int w = 0; w < W; ++w) x[t][w] = xn[t][w];
+        // what the PREVIOUS step's appends returned (issued a whole step ago: no wait), then this step's saved blocks
+        if constexpr (MODE == MODE_SELF) pend_complete();
+        if (rcount) process_ring(step);
         if constexpr (MODE == MODE_SELF) {
-            if (refresh_now) *reinterpret_cast<float4*>(lthr + fresh_at) = make_float4(fresh[0], fresh[1], fresh[2], fresh[3]);
-            if constexpr (ASYNC) {
-                if (look) pend.complete(p, q0, lpop);
+            if (chk_what != ~0u && chk_count >= p.k) {
+                const uint32_t ql = chk_what & 0xFFFFu;
+                lower_threshold(p.thr_live + q0 + ql, (float)((int)(chk_what >> 16) - lpop[ql]));
             }
+            if (refresh_now) *reinterpret_cast<float4*>(lthr + fresh_index()) = make_float4(fresh[0], fresh[1], fresh[2], fresh[3]);
         }
     }
-    if constexpr (MODE == MODE_SELF && ASYNC) pend.complete(p, q0, lpop);
+    if constexpr (MODE == MODE_SELF) pend_complete();
 }
 
 
@@ -509,7 +528,6 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 // the host routes a batch holding an all-zero 64-bit query to the kernel above (Batch::begin, isccsearch.hip).
 constexpr int PK_TILES = 4;                                             // row tiles per wave and step
 constexpr uint32_t PK_DEEP_GROUPS = 6;                                  // chunks of up to this many groups (192 queries) keep four steps of rows in flight
-constexpr uint32_t PK_RING_ENTRIES = 8, PK_RING_ENTRY_DWORDS = 36;      // per wave: saved accumulator blocks of lanes that hold a hit (144 B each)
 __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const h2 x = __builtin_bit_cast(h2, a), y = __builtin_bit_cast(h2, b), z = __builtin_bit_cast(h2, c);
@@ -863,7 +881,6 @@ static void launch_pack_depth(int mode, dim3 grid, size_t lds, hipStream_t st, c
 }
 
 static int launch_pack(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
-    lds += MBLOCK / 64 * PK_RING_ENTRIES * PK_RING_ENTRY_DWORDS * sizeof(uint32_t);       // the waves' rings of saved accumulator blocks
     if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
     if (groups <= PK_DEEP_GROUPS) launch_pack_depth<4>(mode, grid, lds, st, p, groups);
     else launch_pack_depth<1>(mode, grid, lds, st, p, groups);
@@ -891,7 +908,8 @@ uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad, bool pack) {
     return need < max_groups[W] ? need : max_groups[W];
 }
 
-size_t mfma_lds_bytes(int W, uint32_t groups) { return (size_t)groups * W * 64 * 16 + (size_t)groups * 32 * 8; }
+// B fragments | thresholds | popcounts | the four waves' rings of saved result blocks
+size_t mfma_lds_bytes(int W, uint32_t groups) { return (size_t)groups * W * 64 * 16 + (size_t)groups * 32 * 8 + MBLOCK / 64 * PK_RING_ENTRIES * PK_RING_ENTRY_DWORDS * sizeof(uint32_t); }
 
 uint32_t mfma_waves_per_block() { return MBLOCK / 64; }
 uint32_t mfma_rows_per_wave_step(int W, bool pack) { return pack ? 32u * PK_TILES : 32u * (uint32_t)(W == 4 ? mfma_tiles<4>() : 2); }

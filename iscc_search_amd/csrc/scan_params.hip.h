@@ -89,25 +89,4 @@ __device__ __forceinline__ void lower_live(const ScanParams& p, uint32_t qi, int
     else lower_threshold(p.thr_live + qi, (float)thr);
 }
 
-// returns the (possibly lowered) threshold this lane goes on with
-template <bool PACKED = false>
-__device__ __forceinline__ int emit_self(const ScanParams& p, uint32_t qi, int h, uint64_t row, int tau_seen, int popc_q) {
-    // both atomics are in flight together: one round trip to the L2 per candidate (the common case has h == tau_seen or
-    // tau_seen - 1, i.e. none or one counter to bump)
-    uint32_t* const counts = p.ghist + (uint64_t)qi * HB;
-    const bool counted = h < tau_seen;
-    const uint32_t slot = atomicAdd(&p.cnt[(uint64_t)qi * CNT_STRIDE], 1u);
-    uint32_t before = counted ? atomicAdd(&counts[(uint32_t)h], 1u) : 0u;
-    if (slot < p.cap) p.cand[(uint64_t)qi * p.cap + slot] = ((uint64_t)(uint32_t)h << 48) | row;
-    if (!counted) return tau_seen;
-    for (int t = h;;) {
-        if (before + 1 >= p.k) {
-            lower_live<PACKED>(p, qi, t - popc_q);
-            return t;
-        }
-        if (++t >= tau_seen) return tau_seen;
-        before = atomicAdd(&counts[(uint32_t)t], 1u);
-    }
-}
-
 }  // namespace isk
