@@ -53,7 +53,11 @@ typedef const __attribute__((address_space(3))) float* lds_thr_ptr;
 #endif
 template <int W> constexpr int mfma_tiles() { return W == 4 ? ISK_MFMA_TILES_W4 : 2; }
 #ifndef ISK_ORDERED_STAGE
-#define ISK_ORDERED_STAGE 1           // experiment switch: 0 = the builtin-scheduled stage of round 2 for codes of two to four words
+// experiment switch: 1 = the stage of codes of two to four words as single-instruction asm statements in issue order (fold_op /
+// mfma_asm below).  Bit-exact (GPU suite green) but 2-4 % SLOWER than hipcc's own schedule on the same box -- 256-bit 9.0 against
+// 8.8 ms per 1 024 queries, 128-bit 4.63 against 4.45, 192-bit 7.77 against 7.57 (profiles/r03_ab_ordered_stage.txt): with 2 W
+// MFMAs per 17 fold instructions the matrix pipe, not the issue order, is the bound there.  Off.
+#define ISK_ORDERED_STAGE 0
 #endif
 #ifndef ISK_SCALAR_STEPS_FROM_W
 #define ISK_SCALAR_STEPS_FROM_W 2     // experiment switch: code widths (in 64-bit words) from which the step number is kept scalar
@@ -82,9 +86,9 @@ __device__ __forceinline__ float live_threshold(const float* addr) {
 __device__ __forceinline__ uint32_t nibbles(uint32_t x, int j) { return (x >> j) & 0x11111111u; }
 
 // ---- the stage of mfma_scan_kernel for codes of two to four words, in ISSUE ORDER (round 3) ---------------------------------
-// hipcc issued the 2 W MFMAs of a group back to back and the 17-instruction fold of the previous group behind them; the two
-// or three waves of a SIMD then tend to fold at the same time and the matrix pipe idles (0.69 busy at W = 4, 100 M x 256-bit).
-// As in mfma_pack_kernel below, the MFMAs and the fold are single-instruction asm statements in the order they should issue:
+// EXPERIMENT (ISK_ORDERED_STAGE, off by default: measured slower, see the switch).  hipcc issues the 2 W MFMAs of a group back
+// to back and the 17-instruction fold of the previous group behind them.  Here, as in mfma_pack_kernel below, the MFMAs and the
+// fold are single-instruction asm statements in the order they should issue:
 // MFMA (tile 0, word 0), MFMA (tile 1, word 0), then after every further MFMA a few fold instructions of the PREVIOUS group.
 // hipcc places no hazard nops for asm: the fold starts after the stage's second MFMA and walks accumulator 0 of the old group
 // first, so every read of an MFMA result lies >= 12 instructions behind that MFMA (checked by tools/audit_kernels.py).
