@@ -522,7 +522,7 @@ struct Batch {
         }
         cap = std::max<uint32_t>(h->candidate_cap, 16 * k);
         // the self-tightening pass never prunes: ~17 k entries per query over 100 M rows (+ the flood of the first steps)
-        if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0) cap = std::max<uint32_t>(cap, 48 * k);
+        if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0) cap = std::max<uint32_t>(cap, 64 * k);
         multi = jobs.size() > 1;
         P = next_pow2(std::max<uint32_t>(k, 1024));   // select's LDS sort buffer: room for small tie classes (12-20 KB)
         sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
@@ -629,7 +629,11 @@ struct Batch {
             //    queries over 100 M rows against 0.10 ms for the collect pass of the level design.)
             const bool self = allow_self && h->self_tighten && k <= h->self_max_k && use_mfma(s.n);
             used_self = used_self || self;
-            const uint64_t s0 = std::min<uint64_t>(s.n, std::max<uint64_t>(self ? h->self_boot_rows : h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
+            // (the single pass appends everything within the bootstrap threshold until the first update arrives -- 3 072 waves x
+            //  128 rows at once -- so its sample grows with k: 512 k rows measured 4.39 -> 3.80 ms at k = 256 and 11.9 (list
+            //  overflow, retry) -> 5.07 ms at k = 512 against the fixed 65 536, profiles/r03_ab_large_k.txt)
+            const uint64_t s0 = std::min<uint64_t>(s.n, self ? std::max<uint64_t>(h->self_boot_rows, std::min<uint64_t>(512ull * k, s.n / 8))
+                                                             : std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
             isk::BootParams bp{};
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
             bp.queries = h->d_queries.p; bp.bias = h->d_bias.p; bp.cnt = h->d_cnt.p; bp.s0 = s0; bp.nq = nq; bp.k = k; bp.W = j.W; bp.mask_last = j.mask_last;
