@@ -630,9 +630,9 @@ struct Batch {
             const bool self = allow_self && h->self_tighten && k <= h->self_max_k && use_mfma(s.n);
             used_self = used_self || self;
             // (the single pass appends everything within the bootstrap threshold until the first update arrives -- 3 072 waves x
-            //  128 rows at once -- so its sample grows with k: 512 k rows measured 4.39 -> 3.80 ms at k = 256 and 11.9 (list
+            //  128 rows at once -- so its sample grows with k (1 024 k rows): 512 k measured 4.39 -> 3.80 ms at k = 256 and 11.9 (list
             //  overflow, retry) -> 5.07 ms at k = 512 against the fixed 65 536, profiles/r03_ab_large_k.txt)
-            const uint64_t s0 = std::min<uint64_t>(s.n, self ? std::max<uint64_t>(h->self_boot_rows, std::min<uint64_t>(512ull * k, s.n / 8))
+            const uint64_t s0 = std::min<uint64_t>(s.n, self ? std::max<uint64_t>(h->self_boot_rows, std::min<uint64_t>(1024ull * k, s.n / 8))
                                                              : std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
             isk::BootParams bp{};
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
