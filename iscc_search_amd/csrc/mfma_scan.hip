@@ -537,6 +537,12 @@ __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c) {
     const h2 x = __builtin_bit_cast(h2, a), y = __builtin_bit_cast(h2, b), z = __builtin_bit_cast(h2, c);
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_minimum(__builtin_elementwise_minimum(x, y), z));
 }
+// The A operand of 32 bits of a row (mfma_pack_kernel): nibble t of dword j stands for bit j + 4 t, kept IN PLACE -- the codes
+// 0x1, 0x2, 0x4 are e2m1 1/2, 1, 2 (bit 3 would be the sign: that dword moves down one bit) -- and the query fragments carry the
+// reciprocal magnitudes (prologue).  5 vector instructions instead of the 7 of "(x >> j) & 0x11111111, << 1".
+__device__ __forceinline__ v4i pk_rows(uint32_t x) {
+    return v4i{(int)(x & 0x11111111u), (int)(x & 0x22222222u), (int)(x & 0x44444444u), (int)((x & 0x88888888u) >> 1)};
+}
 __device__ __forceinline__ uint32_t live_packed(const float* addr) {
     return (uint32_t)__hip_atomic_load(reinterpret_cast<const int*>(addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -574,7 +580,9 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         const uint32_t g = ql >> 5, c = ql & 31;
         v4i frag;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) frag[j] = (int)((0x22222222u | (nibbles(x, j) << 3)) & (nibbles(m, j) * 0xFu));
+        // +-v with v = 2, 1, 1/2, 1/2 for the four dwords (e2m1 0x4, 0x2, 0x1, 0x1; sign = bit 3): the ROW nibbles of dword j are
+        // 1/2, 1, 2, 2 (pk_rows), so that every product is +-1 and three of a row's four dwords cost ONE v_and each
+        for (int j = 0; j < 4; ++j) frag[j] = (int)(((j == 0 ? 0x44444444u : j == 1 ? 0x22222222u : 0x11111111u) | (nibbles(x, j) << 3)) & (nibbles(m, j) * 0xFu));
         lb[(size_t)g * 64 + hh * 32 + c] = frag;
     }
     for (uint32_t ql = tid; ql < groups * 32; ql += MBLOCK) {
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t)
-            a[t] = v4i{(int)(nibbles(x[t], 0) << 1), (int)(nibbles(x[t], 1) << 1), (int)(nibbles(x[t], 2) << 1), (int)(nibbles(x[t], 3) << 1)};
+            a[t] = pk_rows(x[t]);
         load_rows(ns, x);                                 // the next step's rows, in flight during this one (same registers)
 
         // two B buffers and two accumulator sets: the fragment of group g + 2 is requested while group g + 1 multiplies
