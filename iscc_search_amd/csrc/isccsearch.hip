@@ -167,6 +167,7 @@ struct isccsearch_handle {
     bool mfma = true;
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
+    uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
     int mfma_pack = 1;                // 64-bit codes on the matrix cores: two row tiles per accumulator, packed f16 fold (mfma_pack_kernel)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
     // k <= self_max_k on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
@@ -632,7 +633,7 @@ struct Batch {
             // (the single pass appends everything within the bootstrap threshold until the first update arrives -- 3 072 waves x
             //  128 rows at once -- so its sample grows with k (1 024 k rows): 512 k measured 4.39 -> 3.80 ms at k = 256 and 11.9 (list
             //  overflow, retry) -> 5.07 ms at k = 512 against the fixed 65 536, profiles/r03_ab_large_k.txt)
-            const uint64_t s0 = std::min<uint64_t>(s.n, self ? std::max<uint64_t>(h->self_boot_rows, std::min<uint64_t>(1024ull * k, s.n / 8))
+            const uint64_t s0 = std::min<uint64_t>(s.n, self ? std::max<uint64_t>(h->self_boot_rows, std::min<uint64_t>((uint64_t)h->self_boot_per_k * k, s.n / 8))
                                                              : std::max<uint64_t>(h->boot_rows, std::min<uint64_t>(65536, 64ull * k)));
             isk::BootParams bp{};
             for (uint32_t w = 0; w < j.W; ++w) bp.col[w] = s.col[w];
@@ -1024,6 +1025,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_pack")) { h->mfma_pack = value != 0; return 0; }
+    if (!strcmp(name, "self_boot_per_k")) { if (value < 0 || value > (1 << 20)) return fail(-EINVAL, "self_boot_per_k must be 0..2^20"); h->self_boot_per_k = (uint32_t)value; return 0; }
     if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
     return fail(-EINVAL, "unknown option '%s'", name);
