@@ -207,7 +207,7 @@ def test_self_tightening_pass_equals_levels_and_oracle(hip_engine, nbytes, k):
 def test_an_overflowed_single_pass_is_answered_again_by_the_levels(hip_engine):
     """
     The single pass never prunes its candidate lists (~k ln(n / sample) entries + ties + the first steps' flood).  With the
-    buffer shrunk to 480 entries and a 256-row bootstrap sample (every wave starts under a threshold that ~4 % of the rows
+    buffer shrunk to 640 entries and a 256-row bootstrap sample (every wave starts under a threshold that ~4 % of the rows
     pass) it overflows where the level design, which prunes after every level, still fits: the batch must come back exact,
     through ONE retry and without the per-query exact fallback.
     """
@@ -221,6 +221,7 @@ def test_an_overflowed_single_pass_is_answered_again_by_the_levels(hip_engine):
         t.add(keys, words)
         hip_engine.set_option("candidate_cap", 256)
         hip_engine.set_option("self_boot_rows", 256)
+        hip_engine.set_option("self_boot_per_k", 0)         # (the sample otherwise grows with k)
         try:
             before = hip_engine.stats()
             got = t.search(q, None, k)
@@ -228,7 +229,9 @@ def test_an_overflowed_single_pass_is_answered_again_by_the_levels(hip_engine):
         finally:
             hip_engine.set_option("candidate_cap", 16384)
             hip_engine.set_option("self_boot_rows", 65536)
-        assert after["self_retries"] == before["self_retries"] + 1, "the single pass was expected to overflow its lists"
+            hip_engine.set_option("self_boot_per_k", 1024)
+        delta = {x: after[x] - before[x] for x in ("self_retries", "fallback_queries", "mfma_launches", "mfma_pack_launches", "level_launches", "scan_launches")}
+        assert after["self_retries"] == before["self_retries"] + 1, f"the single pass was expected to overflow its lists: {delta}"
         assert after["fallback_queries"] == before["fallback_queries"], "the level design was expected to fit its lists"
         exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
         for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
