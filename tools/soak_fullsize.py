@@ -36,13 +36,20 @@ def main():
     mismatches = 0
     for rnd in range(rounds):
         nq = int(rng.choice([17, 40, 64, 200, 512, 1000, 1024]))
-        k = int(rng.choice([1, 10, 10, 10, 37, 100, 512]))
+        k = int(rng.choice([1, 10, 10, 10, 37, 100, 256, 512]))
         q = rng.integers(0, 2**64, size=(nq, words), dtype=np.uint64)
         planted = rng.random(nq) < rng.choice([0.0, 0.25, 0.9])
         _, stored = table.export_rows(nbytes, int(rng.integers(0, rows - nq)), nq)
         near = stored.T.copy()
         near[:, words - 1] ^= (np.uint64(1) << rng.integers(0, 4, size=nq).astype(np.uint64)) - np.uint64(1)
         q[planted] = near[planted]
+        # extremes of a dot product (round 3: the packed kernel holds two of them per accumulator): all ones, one bit, and --
+        # every eighth round -- an all-zero query, which sends a 64-bit batch to the unpacked kernel
+        q[0] = ~np.uint64(0)
+        q[1] = 0
+        q[1, 0] = np.uint64(1) << np.uint64(63)
+        if rnd % 8 == 3:
+            q[2] = 0
         if nbytes % 8:
             q[:, words - 1] &= ~np.uint64(0) << np.uint64(8 * (8 - nbytes % 8))
         engine.set_option("mfma", 1)
@@ -52,6 +59,10 @@ def main():
         levels = table.search(q, None, k)
         engine.set_option("self_tighten", 1)
         results = {"levels": levels}
+        if words == 1 and rnd % 2 == 1:           # one-word codes: the unpacked matrix-core kernel as a fourth way
+            engine.set_option("mfma_pack", 0)
+            results["unpacked"] = table.search(q, None, k)
+            engine.set_option("mfma_pack", 1)
         if rnd % 4 == 0:                          # the XOR + popcount kernels take ~13 ms per 1 024 queries: every fourth round
             engine.set_option("mfma", 0)
             results["xor"] = table.search(q, None, k)
