@@ -99,6 +99,9 @@ typedef struct isccsearch_stats {
        again with threshold levels, which prune after every level, before any query took the per-query exact fallback */
     uint64_t self_retries;
     uint64_t mfma_pack_launches; /* how many of mfma_launches ran the packed form (64-bit codes: two row tiles per accumulator) */
+    /* small batches answered by ONE speculative range-limited pass under the previous search's k-th distance / sent on to the
+       ordinary path because a query found fewer than k rows within it (or a list overflowed) */
+    uint64_t spec_hits, spec_misses;
 } isccsearch_stats;
 
 /* Engine lifetime.  One handle drives one GPU (one process per GPU). */
@@ -112,6 +115,8 @@ const char* isccsearch_last_error(void);
  * bootstrapped from max("self_boot_rows" (65 536), "self_boot_per_k" (1 024) x k) rows and looking at the live thresholds every "self_refresh_steps" (1) steps,
  * instead of threshold levels growing by "mfma_level_growth" (4)); "mfma_pack" (0|1, default 1: 64-bit codes run the packed
  * form of that kernel -- two row tiles per accumulator, v_pk_minimum3_f16 fold -- unless the batch holds an all-zero query);
+ * "speculate" (0|1, default 1: a batch of fewer than "mfma_min_queries" queries over a one-segment table is first tried as ONE
+ * range-limited pass under the k-th distance the previous such search ended at + 2, and verified: exact either way);
  * "candidate_cap" (16 384: floor of the per-query candidate
  * buffer, in entries); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
  * (0|1: time every collect-scan launch with HIP events, read back through isccsearch_stats_get), "stretch_mb" (XOR + popcount

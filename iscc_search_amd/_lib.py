@@ -61,6 +61,8 @@ class Stats(ctypes.Structure):
         ("level_ms", ctypes.c_double),
         ("self_retries", ctypes.c_uint64),
         ("mfma_pack_launches", ctypes.c_uint64),
+        ("spec_hits", ctypes.c_uint64),
+        ("spec_misses", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -77,6 +77,9 @@ struct Segment {
     uint64_t freq_rows = 0;        // rows the column was built for (0 = not built)
     uint32_t freq_dup = 0;         // dup_limit it was built with
     void touch() { freq_rows = 0; }
+    // small batches (the reference's per-unit call shape): the k-th distance the last search of this segment ended at -- the next
+    // one tries ONE collect pass under it (+ margin) before the bootstrap / level / pick chain (search_locked)
+    uint32_t spec_k = 0, spec_tau = 0;
 };
 
 struct Table {
@@ -168,6 +171,7 @@ struct isccsearch_handle {
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
+    int speculate = 1;                // small batches: try one range-limited pass under the previous search's k-th distance first
     int mfma_pack = 1;                // 64-bit codes on the matrix cores: two row tiles per accumulator, packed f16 fold (mfma_pack_kernel)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
     // k <= self_max_k on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
@@ -1025,6 +1029,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_pack")) { h->mfma_pack = value != 0; return 0; }
+    if (!strcmp(name, "speculate")) { h->speculate = value != 0; return 0; }
     if (!strcmp(name, "self_boot_per_k")) { if (value < 0 || value > (1 << 20)) return fail(-EINVAL, "self_boot_per_k must be 0..2^20"); h->self_boot_per_k = (uint32_t)value; return 0; }
     if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
@@ -1533,6 +1538,14 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         Batch batch(h, t, m, len, k, d_rec, d_cnt);
         batch.radius = radius;
         if (one_copy) { batch.d_flags = d_cnt + m; batch.h_flags = p_cnt + m; }
+        // (see the speculative branch below) eligible: an ordinary top-k search of a small batch over ONE segment that has been
+        // searched with this k before
+        Segment* spec_seg = nullptr;
+        if (segments == 1)
+            for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) if (t.seg[b].n) spec_seg = &t.seg[b];
+        const bool small_batch = spec_seg && radius < 0 && !out_freq && one_copy && m < h->mfma_min_queries && k <= spec_seg->n;
+        const bool speculate = small_batch && h->speculate && spec_seg->spec_k == k;
+        if (speculate) batch.radius = (int)spec_seg->spec_tau;
         auto copy_results = [&]() -> int {
             if (out_freq) {
                 // only the distinct-asset count of every list leaves the device
@@ -1564,6 +1577,37 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             if ((rc = batch.merge())) return rc;
             if ((rc = copy_results())) return rc;
             HIPOK(hipStreamSynchronize(h->stream));
+        } else if (speculate) {
+            // SPECULATIVE single pass (small batches over one segment).  One query costs boot + level + pick + collect + select:
+            // five launches for what is one pass over the rows (0.22 ms against a 0.13 ms pass).  The k-th distance of similar
+            // queries over the same rows hardly moves, so the pass is first tried as a RANGE-LIMITED search under the distance
+            // the previous search of this segment ended at (+ 2): radius_init + collect + select.  It is exact whenever every
+            // query finds k rows within that radius (its k nearest are then among them); a query that does not, or a list
+            // that overflows, sends the batch through the ordinary path -- nothing is ever returned unverified.
+            bool ok = true;
+            if ((rc = copy_results())) return rc;
+            HIPOK(hipStreamSynchronize(h->stream));
+            if (batch.any_flag()) ok = false;
+            const uint32_t need = (uint32_t)std::min<uint64_t>(k, spec_seg->n);
+            for (uint32_t i = 0; i < m && ok; ++i) ok = p_cnt[i] >= need;
+            if (ok) h->stats.spec_hits += 1;
+            else {
+                h->stats.spec_misses += 1;
+                batch.radius = -1;
+                if ((rc = batch.begin(hq.data()))) return rc;
+                if ((rc = copy_results())) return rc;
+                HIPOK(hipStreamSynchronize(h->stream));
+                if (!batch.jobs.empty() && batch.used_self && batch.any_flag()) {
+                    if ((rc = batch.retry_with_levels(hq.data()))) return rc;
+                    if ((rc = copy_results())) return rc;
+                    HIPOK(hipStreamSynchronize(h->stream));
+                }
+                if (!batch.jobs.empty() && batch.any_flag()) {
+                    if ((rc = batch.fix())) return rc;
+                    if ((rc = copy_results())) return rc;
+                    HIPOK(hipStreamSynchronize(h->stream));
+                }
+            }
         } else {
             // one segment: flags and results travel together, ONE copy and ONE synchronisation per batch
             if (!one_copy && (rc = batch.copy_flags())) return rc;
@@ -1580,6 +1624,15 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 if ((rc = copy_results())) return rc;
                 HIPOK(hipStreamSynchronize(h->stream));
             }
+        }
+        if (small_batch && !batch.jobs.empty()) {
+            // where this batch's lists ended: the next small batch of this segment starts there (+ 2: P(h <= t) grows ~3x per
+            // step at these distances, so the margin costs a handful of candidates and absorbs the spread between queries)
+            uint32_t worst = 0;
+            for (uint32_t i = 0; i < m; ++i)
+                if (p_cnt[i]) worst = std::max<uint32_t>(worst, p_rec[(size_t)i * k + p_cnt[i] - 1].hamming);
+            spec_seg->spec_k = k;
+            spec_seg->spec_tau = std::min<uint32_t>(worst + 2, 8 * ISCCSEARCH_MAX_BYTES);
         }
         if (out_freq) {
             if (batch.jobs.empty()) for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = 0;

@@ -122,3 +122,51 @@ def test_search_many_overflow_takes_the_exact_fallback(hip_engine):
     finally:
         t.drop()
         small.drop()
+
+
+def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hip_engine):
+    """
+    A batch of a few queries over a one-segment table is first tried as ONE range-limited pass under the k-th distance the
+    previous such search ended at (+ 2) and verified (`spec_hits` / `spec_misses`): a hit when the radius holds k rows for every
+    query, the ordinary path when it does not (a query far from everything after queries inside a cluster) or when a list
+    overflows (a cluster of 40 000 near-duplicates inside the radius).  Every answer equals the oracle's.
+    """
+    from oracle import oracle_topk
+
+    rng = np.random.default_rng(77)
+    n, k = 400_000, 10
+    words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+    centre = np.uint64(0x0123456789ABCDEF)
+    cluster = rng.choice(n, size=40_000, replace=False)
+    words[cluster, 0] = centre ^ (np.uint64(1) << rng.integers(0, 64, size=40_000).astype(np.uint64))     # 1 bit off the centre
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
+    t = hip_engine.open_table(0, 1, 8)
+    try:
+        t.add(keys, words)
+
+        def ask(q):
+            q = np.asarray(q, dtype=np.uint64).reshape(-1, 1)
+            before = hip_engine.stats()
+            got = t.search(q, None, k)
+            after = hip_engine.stats()
+            exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+            for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                np.testing.assert_array_equal(g, e, err_msg=name)
+            return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"], int(got[1].max())
+
+        random_q = rng.integers(0, 2**64, size=8, dtype=np.uint64)
+        assert ask(random_q[:1])[:2] == (0, 0)                       # nothing to go by yet
+        hits, misses, worst = ask(random_q[1:2])
+        assert (hits, misses) == (1, 0) and worst >= 10              # the previous search's k-th distance + 2 holds this one's
+        assert ask(random_q[2:6])[:2] == (1, 0)                      # a batch of four
+        assert ask([centre])[:2] == (0, 1)                           # 40 000 rows within the radius: the list overflows -> ordinary path
+        assert ask([centre ^ np.uint64(3)])[:2] == (1, 0)            # k-th distance 1 or 2 now: radius 3 or 4, a few hundred candidates
+        assert ask(random_q[6:7])[:2] == (0, 1)                      # far from the cluster: fewer than k rows within the radius -> ordinary path
+        assert ask(random_q[7:8])[:2] == (1, 0)
+        hip_engine.set_option("speculate", 0)
+        try:
+            assert ask(random_q[:3])[:2] == (0, 0)
+        finally:
+            hip_engine.set_option("speculate", 1)
+    finally:
+        t.drop()
