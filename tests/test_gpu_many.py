@@ -136,9 +136,10 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
     rng = np.random.default_rng(77)
     n, k = 400_000, 10
     words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
-    centre = np.uint64(0x0123456789ABCDEF)
-    cluster = rng.choice(n, size=40_000, replace=False)
-    words[cluster, 0] = centre ^ (np.uint64(1) << rng.integers(0, 64, size=40_000).astype(np.uint64))     # 1 bit off the centre
+    small, big = np.uint64(0x0123456789ABCDEF), np.uint64(0xFEDCBA9876543210)
+    picks = rng.choice(n, size=43_000, replace=False)
+    words[picks[:3_000], 0] = small ^ (np.uint64(1) << rng.integers(0, 64, size=3_000).astype(np.uint64))     # 3 000 rows 1 bit off `small`
+    words[picks[3_000:], 0] = big ^ (np.uint64(1) << rng.integers(0, 64, size=40_000).astype(np.uint64))      # 40 000 rows 1 bit off `big`
     keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
     t = hip_engine.open_table(0, 1, 8)
     try:
@@ -154,15 +155,17 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
                 np.testing.assert_array_equal(g, e, err_msg=name)
             return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"], int(got[1].max())
 
-        random_q = rng.integers(0, 2**64, size=8, dtype=np.uint64)
+        random_q = rng.integers(0, 2**64, size=9, dtype=np.uint64)
         assert ask(random_q[:1])[:2] == (0, 0)                       # nothing to go by yet
         hits, misses, worst = ask(random_q[1:2])
         assert (hits, misses) == (1, 0) and worst >= 10              # the previous search's k-th distance + 2 holds this one's
         assert ask(random_q[2:6])[:2] == (1, 0)                      # a batch of four
-        assert ask([centre])[:2] == (0, 1)                           # 40 000 rows within the radius: the list overflows -> ordinary path
-        assert ask([centre ^ np.uint64(3)])[:2] == (1, 0)            # k-th distance 1 or 2 now: radius 3 or 4, a few hundred candidates
-        assert ask(random_q[6:7])[:2] == (0, 1)                      # far from the cluster: fewer than k rows within the radius -> ordinary path
-        assert ask(random_q[7:8])[:2] == (1, 0)
+        assert ask([big])[:2] == (0, 1)                              # 40 000 rows within the radius: the list overflows -> ordinary path
+        assert ask(random_q[6:7])[:2] == (0, 1)                      # `big` ended at distance 1: radius 3 holds nothing of a random query
+        assert ask([small])[:2] == (1, 0)                            # 3 000 rows within the radius: fits, k of them at distance 1
+        assert ask([small ^ np.uint64(3)])[:2] == (1, 0)             # radius 3: the same 3 000 rows at distance 1 or 3
+        assert ask(random_q[7:8])[:2] == (0, 1)                      # far from the cluster again
+        assert ask(random_q[8:9])[:2] == (1, 0)
         hip_engine.set_option("speculate", 0)
         try:
             assert ask(random_q[:3])[:2] == (0, 0)
