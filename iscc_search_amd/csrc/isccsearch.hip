@@ -1783,6 +1783,8 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         std::unique_ptr<Batch> batch;
         std::vector<uint64_t> hq;
         size_t block_off = 0, rec_bytes = 0;
+        Segment* seg = nullptr;
+        bool small = false, spec = false;
     };
     std::vector<Slot> slots(n);
     std::vector<bool> deferred(n, false);
@@ -1840,6 +1842,11 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         sl.batch.reset(new Batch(h, t, r.nq, len, r.k, d_rec, d_cnt));
         Batch& b = *sl.batch;
         b.radius = r.max_hamming < 0 ? -1 : r.max_hamming;
+        // small top-k batches: the speculative single pass of search_locked (see there), verified in pass 3a
+        for (uint32_t bb = 1; bb <= ISCCSEARCH_MAX_BYTES; ++bb) if (t.seg[bb].n) sl.seg = &t.seg[bb];
+        sl.small = r.max_hamming < 0 && r.nq < h->mfma_min_queries && sl.seg && r.k <= sl.seg->n;
+        sl.spec = sl.small && h->speculate && sl.seg->spec_k == r.k;
+        if (sl.spec) b.radius = (int)sl.seg->spec_tau;
         b.pq_off = pq_off;
         b.d_flags = d_cnt + r.nq;
         b.h_flags = p_cnt + r.nq;
@@ -1861,9 +1868,25 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         if (r.status || r.nq == 0) continue;
         if (!deferred[i]) { ordinary[i] = true; continue; }
         Batch& b = *slots[i].batch;
-        if (!b.jobs.empty() && b.any_flag()) { ordinary[i] = true; continue; }   // rare: exact fallback through the normal path
         const isk::Record* p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p + slots[i].block_off);
         const uint32_t* p_cnt = reinterpret_cast<const uint32_t*>(h->p_block.p + slots[i].block_off + slots[i].rec_bytes);
+        Slot& sl = slots[i];
+        if (sl.spec) {
+            // the speculative pass holds only if every query found k rows within the radius and no list overflowed
+            bool ok = b.jobs.empty() || !b.any_flag();
+            const uint32_t need = (uint32_t)std::min<uint64_t>(r.k, sl.seg->n);
+            for (uint32_t q = 0; q < r.nq && ok; ++q) ok = p_cnt[q] >= need;
+            if (ok) h->stats.spec_hits += 1;
+            else { h->stats.spec_misses += 1; sl.seg->spec_k = 0; ordinary[i] = true; continue; }      // (the ordinary path re-seeds the radius)
+        }
+        if (!b.jobs.empty() && b.any_flag()) { ordinary[i] = true; continue; }   // rare: exact fallback through the normal path
+        if (sl.small && !b.jobs.empty()) {
+            uint32_t worst = 0;
+            for (uint32_t q = 0; q < r.nq; ++q)
+                if (p_cnt[q]) worst = std::max<uint32_t>(worst, p_rec[(size_t)q * r.k + p_cnt[q] - 1].hamming);
+            sl.seg->spec_k = r.k;
+            sl.seg->spec_tau = std::min<uint32_t>(worst + 2, 8 * ISCCSEARCH_MAX_BYTES);
+        }
         unpack_records(p_rec, p_cnt, r.nq, r.k, h->tables[r.table]->key_words, nullptr, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count);
     }
     // pass 3b: overflowed and non-deferred requests run the ordinary pipeline

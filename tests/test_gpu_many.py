@@ -166,6 +166,23 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
         assert ask([small ^ np.uint64(3)])[:2] == (1, 0)             # radius 3: the same 3 000 rows at distance 1 or 3
         assert ask(random_q[7:8])[:2] == (0, 1)                      # far from the cluster again
         assert ask(random_q[8:9])[:2] == (1, 0)
+        # the per-unit searches of one search_assets request (isccsearch_search_many) speculate the same way, verified after their
+        # one synchronisation: two requests hit, then a far query after a clustered one misses and is answered by the ordinary path
+        def ask_many(qs):
+            reqs = [(t, np.asarray([q], dtype=np.uint64).reshape(1, 1), None, k, None) for q in qs]
+            before = hip_engine.stats()
+            outs = hip_engine.search_many(reqs)
+            after = hip_engine.stats()
+            for (_, q, _, _, _), got in zip(reqs, outs):
+                exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+                for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                    np.testing.assert_array_equal(g, e, err_msg=name)
+            return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"]
+
+        assert ask_many(random_q[:2]) == (2, 0)
+        assert ask_many([small]) == (1, 0)
+        assert ask_many(random_q[2:4]) == (0, 2)                     # both were enqueued under radius 3
+        assert ask_many(random_q[4:6]) == (2, 0)
         hip_engine.set_option("speculate", 0)
         try:
             assert ask(random_q[:3])[:2] == (0, 0)
