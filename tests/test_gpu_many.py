@@ -181,7 +181,7 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
 
         assert ask_many(random_q[:2]) == (2, 0)
         assert ask_many([small]) == (1, 0)
-        assert ask_many(random_q[2:4]) == (0, 2)                     # both were enqueued under radius 3
+        assert ask_many(random_q[2:4]) == (1, 2)                     # both were enqueued under radius 3; the second one's rerun already profits from the first one's
         assert ask_many(random_q[4:6]) == (2, 0)
         hip_engine.set_option("speculate", 0)
         try:
