@@ -94,8 +94,7 @@ class HipEngine:
         (``isccsearch_merge_device_after``); a count of ``_lib.COUNT_OVERFLOW`` then marks a query some shard could not
         complete asynchronously.
         """
-        out = _alloc_out(nq, k, key_words)
-        outs = (_lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32), _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32))
+        out, outs = _alloc_out(nq, k, key_words)
         args = (self.handle, n_lists, nq, k, key_words, ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr), list_stride, count_stride)
         if after_stream is None:
             _lib.check(self._lib.isccsearch_merge_device(*args, *outs))
@@ -121,18 +120,15 @@ class HipEngine:
             q_words = table._words(q_words)
             nq = q_words.shape[0]
             q_nbytes = table._nbytes(q_nbytes, nq)
-            out = _alloc_out(nq, k, table.key_words)
+            out, addr = _alloc_out(nq, k, table.key_words)
             keep.append((q_words, q_nbytes))
             outs.append(out)
             r = arr[i]
             r.table, r.nq, r.k = table.id, nq, k
             r.max_hamming = -1 if max_hamming is None else int(max_hamming)
-            r.q_words = q_words.ctypes.data
-            r.q_nbytes = q_nbytes.ctypes.data if q_nbytes is not None else None
-            r.out_keys = out[0].ctypes.data
-            r.out_hamming = out[1].ctypes.data
-            r.out_prefix_bits = out[2].ctypes.data
-            r.out_count = out[3].ctypes.data
+            r.q_words = _lib.ptr(q_words)
+            r.q_nbytes = _lib.ptr(q_nbytes)
+            r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count = addr
         _lib.check(self._lib.isccsearch_search_many(self.handle, n, arr))
         return outs
 
@@ -152,13 +148,22 @@ class HipEngine:
 
 
 def _alloc_out(nq, k, key_words):
+    """The four result arrays of a search as views of ONE zeroed allocation, and their addresses (one lookup instead of four)."""
+    nk = nq * k
+    o_ham = nk * 8 * key_words
+    o_pre = o_ham + nk * 4
+    o_cnt = (o_pre + nk * 2 + 3) & ~3
+    buf = np.zeros(o_cnt + nq * 4 + 8, dtype=np.uint8)
+    base = buf.__array_interface__["data"][0]
+    pad = -base & 7                                      # numpy aligns to 16 in practice; be exact anyway
     shape = (nq, k, 2) if key_words == 2 else (nq, k)
-    return (
-        np.zeros(shape, dtype=np.uint64),
-        np.zeros((nq, k), dtype=np.uint32),
-        np.zeros((nq, k), dtype=np.uint16),
-        np.zeros(nq, dtype=np.uint32),
+    out = (
+        buf[pad : pad + o_ham].view(np.uint64).reshape(shape),
+        buf[pad + o_ham : pad + o_pre].view(np.uint32).reshape(nq, k),
+        buf[pad + o_pre : pad + o_pre + nk * 2].view(np.uint16).reshape(nq, k),
+        buf[pad + o_cnt : pad + o_cnt + nq * 4].view(np.uint32),
     )
+    return out, (base + pad, base + pad + o_ham, base + pad + o_pre, base + pad + o_cnt)
 
 
 class HipTable:
@@ -285,15 +290,9 @@ class HipTable:
         if k < 1:
             raise ValueError("`count` must be >= 1")
         q_nbytes = self._nbytes(q_nbytes, nq)
-        out = _alloc_out(nq, k, self.key_words)
+        out, addr = _alloc_out(nq, k, self.key_words)
         if nq:
-            _lib.check(
-                self.engine._lib.isccsearch_search(
-                    self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k,
-                    _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32),
-                    _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32),
-                )
-            )
+            _lib.check(self.engine._lib.isccsearch_search(self.engine.handle, self.id, nq, _lib.ptr(q_words), _lib.ptr(q_nbytes), k, *addr))
         return out
 
     def search_within(self, q_words, q_nbytes, k, max_hamming):
@@ -308,15 +307,9 @@ class HipTable:
         if k < 1:
             raise ValueError("`count` must be >= 1")
         q_nbytes = self._nbytes(q_nbytes, nq)
-        out = _alloc_out(nq, k, self.key_words)
+        out, addr = _alloc_out(nq, k, self.key_words)
         if nq:
-            _lib.check(
-                self.engine._lib.isccsearch_search_within(
-                    self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k,
-                    int(max_hamming), _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32),
-                    _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32),
-                )
-            )
+            _lib.check(self.engine._lib.isccsearch_search_within(self.engine.handle, self.id, nq, _lib.ptr(q_words), _lib.ptr(q_nbytes), k, int(max_hamming), *addr))
         return out
 
     def doc_freq(self, q_words, q_nbytes=None, dup_limit=1000):
