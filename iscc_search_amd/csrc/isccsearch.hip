@@ -554,7 +554,10 @@ struct Batch {
         memset(pq, 0, (size_t)nq_pad * 4 * 8);
         for (uint32_t q = 0; q < nq; ++q)
             for (int w = 0; w < t.max_words; ++w) pq[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
-        HIPOK(hipMemcpyAsync(h->d_queries.p, pq, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
+        // (a range-limited search of <= 16 queries over one segment -- the speculative single pass of search_locked -- carries its
+        //  queries in the ARGUMENTS of its first kernel, which writes them to d_queries: one stream operation less, ~8 us of 170)
+        const bool inline_queries = radius >= 0 && nq_pad <= isk::INLINE_QUERIES && jobs.size() == 1;
+        if (!inline_queries) HIPOK(hipMemcpyAsync(h->d_queries.p, pq, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
         if (mark_overflow) { HIPOK(hipEventRecord(h->ev_staged, h->stream)); h->ev_staged_pending = true; }
 
         for (size_t ji = 0; ji < jobs.size(); ++ji) {
@@ -618,6 +621,12 @@ struct Batch {
 
             if (radius >= 0) {
                 // range-limited search: the threshold is given, so one streaming pass collects everything
+                if (inline_queries) {
+                    isk::InlineQueries iq;
+                    memcpy(iq.w, pq, (size_t)nq_pad * 4 * 8);
+                    hipLaunchKernelGGL(isk::radius_init_inline_kernel, dim3(1), dim3(isk::BLOCK), 0, h->stream,
+                                       h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)radius, h->d_queries.p, iq);
+                } else
                 hipLaunchKernelGGL(isk::radius_init_kernel, dim3((nq_pad + isk::BLOCK - 1) / isk::BLOCK), dim3(isk::BLOCK), 0, h->stream,
                                    h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)radius);
                 if ((rc = collect_from(0))) return rc;

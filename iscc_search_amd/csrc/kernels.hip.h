@@ -494,6 +494,19 @@ __global__ __launch_bounds__(BLOCK) void radius_init_kernel(uint32_t* bias, uint
     cnt[(uint64_t)q * CNT_STRIDE] = 0;
 }
 
+// ... and for a handful of queries the queries themselves, carried in the kernel's arguments ([nq_pad][4] words)
+constexpr uint32_t INLINE_QUERIES = 16;
+struct InlineQueries { uint64_t w[INLINE_QUERIES * 4]; };
+__global__ __launch_bounds__(BLOCK) void radius_init_inline_kernel(uint32_t* bias, uint32_t* cnt, uint32_t nq, uint32_t nq_pad, uint32_t value,
+                                                                   uint64_t* queries, const InlineQueries iq) {
+    const uint32_t i = threadIdx.x;
+    if (i < nq_pad * 4) queries[i] = iq.w[i];
+    if (i < nq_pad) {
+        bias[i] = i < nq ? value : BIAS_NEVER;
+        cnt[(uint64_t)i * CNT_STRIDE] = 0;
+    }
+}
+
 struct BootParams {
     const uint64_t* col[4];
     const uint64_t* queries;  // [nq_pad][4]
