@@ -172,6 +172,7 @@ struct isccsearch_handle {
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
     int speculate = 1;                // small batches: try one range-limited pass under the previous search's k-th distance first
+    uint32_t spec_max_queries = 16;   // ... batches of up to this many queries
     int mfma_pack = 1;                // 64-bit codes on the matrix cores: two row tiles per accumulator, packed f16 fold (mfma_pack_kernel)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
     // k <= self_max_k on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --
@@ -1039,6 +1040,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_pack")) { h->mfma_pack = value != 0; return 0; }
     if (!strcmp(name, "speculate")) { h->speculate = value != 0; return 0; }
+    if (!strcmp(name, "spec_max_queries")) { if (value < 0 || value > 1024) return fail(-EINVAL, "spec_max_queries must be 0..1024"); h->spec_max_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_boot_per_k")) { if (value < 0 || value > (1 << 20)) return fail(-EINVAL, "self_boot_per_k must be 0..2^20"); h->self_boot_per_k = (uint32_t)value; return 0; }
     if (!strcmp(name, "mfma_min_rows")) { if (value < 1) return fail(-EINVAL, "mfma_min_rows must be >= 1"); h->mfma_min_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "sample_cost")) return 0;   // accepted for compatibility: the levels no longer re-read rows, nothing to balance
@@ -1552,7 +1554,7 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         Segment* spec_seg = nullptr;
         if (segments == 1)
             for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) if (t.seg[b].n) spec_seg = &t.seg[b];
-        const bool small_batch = spec_seg && radius < 0 && !out_freq && one_copy && m < h->mfma_min_queries && k <= spec_seg->n;
+        const bool small_batch = spec_seg && radius < 0 && !out_freq && one_copy && m <= h->spec_max_queries && k <= spec_seg->n;
         const bool speculate = small_batch && h->speculate && spec_seg->spec_k == k;
         if (speculate) batch.radius = (int)spec_seg->spec_tau;
         auto copy_results = [&]() -> int {
@@ -1853,7 +1855,7 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         b.radius = r.max_hamming < 0 ? -1 : r.max_hamming;
         // small top-k batches: the speculative single pass of search_locked (see there), verified in pass 3a
         for (uint32_t bb = 1; bb <= ISCCSEARCH_MAX_BYTES; ++bb) if (t.seg[bb].n) sl.seg = &t.seg[bb];
-        sl.small = r.max_hamming < 0 && r.nq < h->mfma_min_queries && sl.seg && r.k <= sl.seg->n;
+        sl.small = r.max_hamming < 0 && r.nq <= h->spec_max_queries && sl.seg && r.k <= sl.seg->n;
         sl.spec = sl.small && h->speculate && sl.seg->spec_k == r.k;
         if (sl.spec) b.radius = (int)sl.seg->spec_tau;
         b.pq_off = pq_off;
