@@ -42,6 +42,7 @@
 namespace isk {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(3))) v4i* lds_frag_ptr;
@@ -638,11 +639,13 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     };
     auto process_ring = [&](uint64_t st) {
         const uint32_t reg = lane >> 1, hf = lane & 1;
-        const uint32_t off0 = (2 * (reg >> 4) + hf) * 32 + (reg & 3) + 8 * ((reg & 15) >> 2);
+        // result `reg` of half `hf` is tile 2 (reg >> 4) + hf, matrix row (reg & 3) + 8 ((reg & 15) >> 2) + 4 (lane >> 5 of the
+        // saving lane); tile t, matrix row m is row 64 (t & 1) + (t >> 1) + 2 m of the step (`expand`)
+        const uint32_t off0 = 64 * hf + (reg >> 4) + 2 * ((reg & 3) + 8 * ((reg & 15) >> 2));
         for (uint32_t e = 0; e < rcount; ++e) {
             const uint32_t* const blk = ring + e * ENTRY;
             const uint32_t bits = blk[reg], head = blk[32], tpk = blk[33];
-            const uint32_t ql = head & 0xFFFFu, off = off0 + 4 * (head >> 16);
+            const uint32_t ql = head & 0xFFFFu, off = off0 + 8 * (head >> 16);
             const bool below = hf ? bits < (tpk & 0xFFFF0000u) : (bits & 0xFFFFu) < (tpk & 0xFFFFu);
             const int d = hf ? (int)(bits >> 16) - (int)PK_HI0 : (int)(bits & 0xFFFFu) - (int)PK_LO0;
             const uint64_t row = st * (32 * MT) + off;
@@ -770,22 +773,40 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
 
     const v4i* const lbl = lb + lane;
     const uint32_t* const lt = lthr + r;
-    auto row_of = [&](uint64_t st, int t) { const uint64_t row = (st * MT + t) * 32 + r; return row <= last_row ? row : last_row; };
-    // lane (r, h) of tile t reads dword h of row st * 128 + 32 t + r: a uniform base plus a constant per-lane offset; only the
-    // table's last step can be partial and clamps per lane
-    const uint32_t lane_dword = r * 2 + h;
-    auto load_rows = [&](uint64_t st, uint32_t (&dst)[MT]) {
-        if ((st + 1) * (32 * MT) <= p.n_rows) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t) dst[t] = (col32 + st * (64 * MT) + t * 64)[lane_dword];
-        } else {
-#pragma unroll
-            for (int t = 0; t < MT; ++t) dst[t] = col32[row_of(st, t) * 2 + h];
-        }
+    // A step is 128 rows = 1 KB, ONE 16-byte load per lane: lane L holds rows 2 L and 2 L + 1 of the step (x, y | z, w).  The
+    // matrix-core operand wants a row's two dwords in lanes m and m + 32: v_permlane32_swap (gfx950) trades the upper half of
+    // one register with the lower half of another, so swap(x, y) yields TWO tiles at once -- rows 2 m (lanes < 32 kept their x,
+    // lanes >= 32 received y of lane m) and rows 2 m + 64 -- and swap(z, w) the tiles of rows 2 m + 1 and 2 m + 65.  Before:
+    // four 4-byte loads per lane and step, four times the address work of the texture path for the same bytes.
+    auto load_rows = [&](uint64_t st) -> u32x4 {          // compiler-scheduled: DEPTH == 1, and the table's partial last step
+        if ((st + 1) * (32 * MT) <= p.n_rows) return reinterpret_cast<const u32x4*>(col32 + st * (64 * MT))[lane];
+        const uint64_t r0 = st * (32 * MT) + 2 * lane, r1 = r0 + 1;
+        const uint2 lo = *reinterpret_cast<const uint2*>(col32 + (r0 <= last_row ? r0 : last_row) * 2);
+        const uint2 hi = *reinterpret_cast<const uint2*>(col32 + (r1 <= last_row ? r1 : last_row) * 2);
+        return u32x4{lo.x, lo.y, hi.x, hi.y};
     };
-    uint32_t x[DEPTH][MT];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_rows(step + d * stride < nsteps ? step + d * stride : step, x[d]);
+    auto expand = [&](const u32x4& v) {
+        const auto e = __builtin_amdgcn_permlane32_swap(v[0], v[1], false, false);
+        const auto o = __builtin_amdgcn_permlane32_swap(v[2], v[3], false, false);
+        a[0] = pk_rows(e[0]);
+        a[1] = pk_rows(e[1]);
+        a[2] = pk_rows(o[0]);
+        a[3] = pk_rows(o[1]);
+    };
+    // DEPTH > 1: the loads are issued from inline asm and retired by COUNTED waits, so that DEPTH steps of rows stay in flight.
+    // (Left to hipcc, every step began with s_waitcnt vmcnt(0) and a copy of the whole row-register array: nothing was in flight
+    //  while a step computed, and 17..64 queries scanned at 3.4 TB/s.)  Same discipline as load_tile_asm (kernels.hip.h), checked
+    // at build time by tools/audit_kernels.py: nothing touches a destination between its load and its wait; `s_nop 4` in front
+    // (a VALU-written SGPR base needs 5 wait states before a VMEM instruction reads it); no spills in this kernel.
+    const uint32_t lane_bytes = lane * 16;
+    auto issue_rows = [&](u32x4& dst, uint64_t st) {
+        const unsigned char* const base = reinterpret_cast<const unsigned char*>(col32) + st * (256 * MT);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2\n\t" : "=&v"(dst) : "v"(lane_bytes), "s"(base) : "memory");
+    };
+    auto await_rows = [&](u32x4& v) {                     // DEPTH - 1 younger row loads are outstanding at every wait
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+        asm volatile("" : "+v"(v));
+    };
     const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     // thresholds [256 wave, 256 wave + 256) are this wave's to keep fresh, four per lane.  The lane number is RECOMPUTED at
     // each use (mbcnt of a laundered zero), or hipcc keeps a 64-bit global address and an LDS address alive through the
@@ -804,8 +825,8 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     const uint32_t slices = groups * 32 * 4 / 64, nwaves = gridDim.x * (MBLOCK / 64);
     const uint32_t gw = blockIdx.x * (MBLOCK / 64) + wave_s;
     uint32_t trip = 0;
-    auto one_step = [&](uint32_t (&x)[MT]) {
-        const uint64_t ns = step + DEPTH * stride < nsteps ? step + DEPTH * stride : step;
+    // one step over the rows expanded in a[]
+    auto one_step = [&]() {
         uint32_t fresh[4] = {0u, 0u, 0u, 0u};
         const bool look = trip < 4 || (trip & refresh_mask) == 0;
         const bool refresh_now = refresh && look;
@@ -829,11 +850,6 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-            a[t] = pk_rows(x[t]);
-        load_rows(ns, x);                                 // the next step's rows, in flight during this one (same registers)
-
         // two B buffers and two accumulator sets: the fragment of group g + 2 is requested while group g + 1 multiplies
         // (any number of groups: pairs of stages while at least three groups remain, then one stage + the last fold for an even
         //  rest or the last fold alone for an odd one -- 17..32 queries are ONE group, not one and a padding group)
@@ -872,13 +888,38 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
             if (refresh_now) *reinterpret_cast<uint4*>(lthr + fresh_index()) = make_uint4(fresh[0], fresh[1], fresh[2], fresh[3]);
         }
     };
-    while (step < nsteps) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (step >= nsteps) break;
-            one_step(x[d]);
+    if constexpr (DEPTH == 1) {
+        u32x4 x = load_rows(step);
+        while (step < nsteps) {
+            expand(x);
+            x = load_rows(step + stride < nsteps ? step + stride : step);        // in flight during this step
+            one_step();
             step += stride;
             ++trip;
+        }
+    } else {
+        const uint64_t nfull = p.n_rows / (32 * MT);          // whole steps: [first, nfull); a partial last step is loaded the slow way
+        u32x4 x[DEPTH];
+        if (step < nfull) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) issue_rows(x[d], step + d * stride < nfull ? step + d * stride : step);
+            while (step < nfull) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    if (step >= nfull) break;
+                    await_rows(x[d]);
+                    expand(x[d]);
+                    issue_rows(x[d], step + DEPTH * stride < nfull ? step + DEPTH * stride : step);     // (past the end: a re-read nobody uses)
+                    one_step();
+                    step += stride;
+                    ++trip;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (step < nsteps) {                                  // == nfull: this wave owns the partial step
+            expand(load_rows(step));
+            one_step();
         }
     }
     if constexpr (MODE == MODE_SELF) pend_complete();

@@ -107,13 +107,16 @@ def audit_loads(name, ins):
         # tile's loads have been issued, and whether EXEC is known to be zero (the taken side of s_cbranch_execz, until
         # something writes EXEC: hipcc structurises the loop's `break` tests that way, and vector instructions executed
         # with EXEC = 0 neither read nor write anything -- v_readlane / v_readfirstlane excepted).
-        todo, seen = [(end, False, False)], set()
+        # `younger`: asm loads issued since the group.  Loads return in order, so an asm `s_waitcnt vmcnt(N)` retires the group
+        # once at least N younger loads have been issued (two buffers: the other tile's U*W loads and vmcnt(U*W); a ring of
+        # DEPTH one-load slots: DEPTH - 1 younger loads and vmcnt(DEPTH - 1)).
+        todo, seen = [(end, 0, False)], set()
         while todo:
-            i, next_seen, exec0 = todo.pop()
+            i, younger, exec0 = todo.pop()
             while i < len(ins):
-                if (i, next_seen, exec0) in seen:
+                if (i, younger, exec0) in seen:
                     break
-                seen.add((i, next_seen, exec0))
+                seen.add((i, younger, exec0))
                 text, in_asm = ins[i]
                 if text.endswith(":"):
                     i += 1
@@ -132,11 +135,12 @@ def audit_loads(name, ins):
                         for k in range(g[0], g[1]):
                             if vregs(ins[k][0]) & dests:
                                 bad.append(f"{name}: load group at #{g[0]} touches in-flight destinations of the group at #{start}: {ins[k][0]}")
-                        next_seen = True
+                    # (counted on the EXEC = 0 paths too: what they skip is the vector work, not the wave's instruction stream)
+                    younger = min(younger + sum(1 for k in range(g[0], g[1]) if ins[k][0].startswith("global_load_dword")), 64)
                     i = g[1]
                     continue
                 m = re.match(r"s_waitcnt\b.*vmcnt\((\d+)\)", text)
-                if m and (int(m.group(1)) == 0 or (in_asm and next_seen)):
+                if m and (int(m.group(1)) == 0 or (in_asm and younger and int(m.group(1)) <= younger)):
                     break                                   # retired on this path
                 if text.startswith("s_endpgm"):
                     break
@@ -157,7 +161,7 @@ def audit_loads(name, ins):
                     if bm.group(1) == "s_branch":
                         i = target
                         continue
-                    todo.append((target, next_seen, True if bm.group(1) == "s_cbranch_execz" else exec0))
+                    todo.append((target, younger, True if bm.group(1) == "s_cbranch_execz" else exec0))
                     if bm.group(1) == "s_cbranch_execnz":
                         exec0 = True                        # falling through an execnz branch: EXEC is zero
                 i += 1
@@ -282,7 +286,7 @@ def main():
     n_groups = 0
     n_kernels = 0
     for name, ins in kernels.items():
-        if "scan_kernel" in name or "scan_adapt_kernel" in name:
+        if "scan_kernel" in name or "scan_adapt_kernel" in name or "mfma_pack_kernel" in name:
             b, n = audit_loads(name, ins)
             bad += b
             if n:
