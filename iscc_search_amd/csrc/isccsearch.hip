@@ -172,7 +172,7 @@ struct isccsearch_handle {
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
     int speculate = 1;                // small batches: try one range-limited pass under the previous search's k-th distance first
-    uint32_t spec_max_queries = 16;   // ... batches of up to this many queries
+    uint32_t spec_max_queries = 128;   // ... batches of up to this many queries
     int mfma_pack = 1;                // 64-bit codes on the matrix cores: two row tiles per accumulator, packed f16 fold (mfma_pack_kernel)
     uint64_t mfma_min_rows = 65536;   // launches over fewer rows do not amortise the per-block query expansion
     // k <= self_max_k on the matrix cores: ONE pass whose thresholds tighten themselves (MODE_SELF) instead of levels + picks --

@@ -531,6 +531,9 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 //
 // d2 = +64 (query == 0 against a row of all ones) would carry into the exponent and halve the resolution of the low half:
 // the host routes a batch holding an all-zero 64-bit query to the kernel above (Batch::begin, isccsearch.hip).
+#ifndef ISK_PACK_STRETCH
+#define ISK_PACK_STRETCH 1
+#endif
 constexpr int PK_TILES = 4;                                             // row tiles per wave and step
 constexpr uint32_t PK_DEEP_GROUPS = 6;                                  // chunks of up to this many groups (192 queries) keep four steps of rows in flight
 __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c) {
@@ -557,7 +560,9 @@ __device__ __forceinline__ uint32_t live_packed(const float* addr) {
 // 12 KB per CU) in flight the scan crawled at 2.5 TB/s, bound by memory latency (32 queries: 0.33 ms per 100 M rows,
 // profiles/r03_step_timelines.txt).  Small chunks run the DEPTH = 4 instantiation: the step body four times per loop trip,
 // each on its own row registers.
-template <int MODE, int DEPTH>
+// G: 0 = any number of groups, fragments from LDS, a step's groups pipelined among themselves; 1 / 2 = a chunk of exactly that
+// many groups (<= 64 queries), fragments in registers, pipelined ACROSS steps (`few_step` below)
+template <int MODE, int DEPTH, int G>
 __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p, const uint32_t groups) {
     constexpr int MT = PK_TILES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -603,7 +608,9 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     const uint64_t nsteps = (p.n_rows + 32 * MT - 1) / (32 * MT);
     const uint64_t stride = (uint64_t)gridDim.x * (MBLOCK / 64);
     // the wave number as a SCALAR: step number and row addresses then live on the scalar unit (scalar-base loads)
-    uint64_t step = first + (uint64_t)blockIdx.x * (MBLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    // (DEPTH > 1: a wave owns STRETCH consecutive steps at a time -- its loads in flight are DEPTH KB of one stretch of rows)
+    constexpr int STRETCH = ISK_PACK_STRETCH ? DEPTH : 1;
+    uint64_t step = first + ((uint64_t)blockIdx.x * (MBLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave)) * STRETCH;
     if (step >= nsteps) return;
     const uint64_t last_row = p.n_rows - 1;
     const uint32_t* const col32 = reinterpret_cast<const uint32_t*>(p.col[0]);
@@ -630,14 +637,14 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     // (The lane whose own increment crossed k used to do that: two returned atomics and a dependent chain of further ones per
     //  candidate, ~3.6 us of wave time each -- the level design beat the single pass by 10 % at 100 M rows and by 40 % at 12.5 M.)
     uint32_t pend_slot = 0, pend_lo = 0, pend_hi = 0x80000000u;        // pend_hi bit 31: nothing pending
-    auto pend_complete = [&]() {
+    auto pend_complete = [&]() __attribute__((always_inline)) {
         if (!(pend_hi & 0x80000000u)) {
             const uint32_t qi = q0 + (pend_hi >> 20);                   // query in chunk : 11 | hamming : 7 | row >> 32 : 12 ... see issue below
             if (pend_slot < p.cap) p.cand[(uint64_t)qi * p.cap + pend_slot] = ((uint64_t)((pend_hi >> 12) & 0x7Fu) << 48) | ((uint64_t)(pend_hi & 0xFFFu) << 32) | pend_lo;
             pend_hi = 0x80000000u;
         }
     };
-    auto process_ring = [&](uint64_t st) {
+    auto process_ring = [&](uint64_t st) __attribute__((always_inline)) {
         const uint32_t reg = lane >> 1, hf = lane & 1;
         // result `reg` of half `hf` is tile 2 (reg >> 4) + hf, matrix row (reg & 3) + 8 ((reg & 15) >> 2) + 4 (lane >> 5 of the
         // saving lane); tile t, matrix row m is row 64 (t & 1) + (t >> 1) + 2 m of the step (`expand`)
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         rcount = 0;
     };
     // `mask`: the lanes whose fold differs from T (query g * 32 + (lane & 31), rows 4 * (lane >> 5) + ... of the step's tiles)
-    auto save_hits = [&](const Acc& acc, uint64_t mask, uint32_t tpk, uint32_t g, uint64_t st) {
+    auto save_hits = [&](const Acc& acc, uint64_t mask, uint32_t tpk, uint32_t g, uint64_t st) __attribute__((always_inline)) {
         while (mask) {                              // wave-uniform; more than one trip only when the ring fills up
             const uint32_t room = RING_E - rcount;
             if (room == 0) { process_ring(st); continue; }
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
 
     // stage: MFMAs of the NEW group into `nw`, fold of the OLD group `od` with its packed threshold; returns the lanes whose
     // fold differs from T as a wave mask and the fold in `m`
-    auto stage = [&](Acc& nw, const Acc& od, const v4i& b, uint32_t tpk, uint32_t& m) -> uint64_t {
+    auto stage = [&](Acc& nw, const Acc& od, const v4i& b, uint32_t tpk, uint32_t& m) __attribute__((always_inline)) -> uint64_t {
         uint32_t mA, mB;
         uint64_t mask;
         const v16f& o0 = od.t[0];
@@ -736,13 +743,13 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         return mask;
     };
     // the four MFMAs of a step's FIRST group (nothing to fold beside them), padded so that the first stage may read them
-    auto first_group = [&](Acc& nw, const v4i& b) {
+    auto first_group = [&](Acc& nw, const v4i& b) __attribute__((always_inline)) {
         asm volatile(ISK_MF1(n0, a0) ISK_MF1(n1, a2) ISK_MF2(n0, a1) ISK_MF2(n1, a3) "s_nop 7\ns_nop 3\n"
                      : [n0] "=&v"(nw.t[0]), [n1] "=&v"(nw.t[1])
                      : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b] "v"(b), [mg] "v"(magic), [sh] "v"(sc_hi), [so] "v"(sc_one));
     };
     // the fold of a step's LAST group: same order as in a stage, no MFMA beside it
-    auto last_fold = [&](const Acc& od, uint32_t tpk, uint32_t& m) -> uint64_t {
+    auto last_fold = [&](const Acc& od, uint32_t tpk, uint32_t& m) __attribute__((always_inline)) -> uint64_t {
         uint32_t mA, mB;
         uint64_t mask;
         const v16f& o0 = od.t[0];
@@ -778,14 +785,14 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     // one register with the lower half of another, so swap(x, y) yields TWO tiles at once -- rows 2 m (lanes < 32 kept their x,
     // lanes >= 32 received y of lane m) and rows 2 m + 64 -- and swap(z, w) the tiles of rows 2 m + 1 and 2 m + 65.  Before:
     // four 4-byte loads per lane and step, four times the address work of the texture path for the same bytes.
-    auto load_rows = [&](uint64_t st) -> u32x4 {          // compiler-scheduled: DEPTH == 1, and the table's partial last step
+    auto load_rows = [&](uint64_t st) __attribute__((always_inline)) -> u32x4 {          // compiler-scheduled: DEPTH == 1, and the table's partial last step
         if ((st + 1) * (32 * MT) <= p.n_rows) return reinterpret_cast<const u32x4*>(col32 + st * (64 * MT))[lane];
         const uint64_t r0 = st * (32 * MT) + 2 * lane, r1 = r0 + 1;
         const uint2 lo = *reinterpret_cast<const uint2*>(col32 + (r0 <= last_row ? r0 : last_row) * 2);
         const uint2 hi = *reinterpret_cast<const uint2*>(col32 + (r1 <= last_row ? r1 : last_row) * 2);
         return u32x4{lo.x, lo.y, hi.x, hi.y};
     };
-    auto expand = [&](const u32x4& v) {
+    auto expand = [&](const u32x4& v) __attribute__((always_inline)) {
         const auto e = __builtin_amdgcn_permlane32_swap(v[0], v[1], false, false);
         const auto o = __builtin_amdgcn_permlane32_swap(v[2], v[3], false, false);
         a[0] = pk_rows(e[0]);
@@ -799,11 +806,16 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     // at build time by tools/audit_kernels.py: nothing touches a destination between its load and its wait; `s_nop 4` in front
     // (a VALU-written SGPR base needs 5 wait states before a VMEM instruction reads it); no spills in this kernel.
     const uint32_t lane_bytes = lane * 16;
-    auto issue_rows = [&](u32x4& dst, uint64_t st) {
-        const unsigned char* const base = reinterpret_cast<const unsigned char*>(col32) + st * (256 * MT);
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2\n\t" : "=&v"(dst) : "v"(lane_bytes), "s"(base) : "memory");
+    auto issue_rows = [&](u32x4& dst, uint64_t st) __attribute__((always_inline)) {
+        const uint64_t addr = reinterpret_cast<uint64_t>(col32) + st * (256 * MT);
+        // (the step number is wave-uniform by construction; pinned to SGPRs here in case hipcc moved its arithmetic to the VALU)
+        const unsigned char* const base = reinterpret_cast<const unsigned char*>(
+            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr));
+        // ("+v": a slot is ONE register quadruple for the whole kernel, updated in place -- as a fresh output per load, hipcc gave
+        //  some instantiations' slots different registers in the loop and rotated them with copies at the back edge, in flight)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2\n\t" : "+v"(dst) : "v"(lane_bytes), "s"(base) : "memory");
     };
-    auto await_rows = [&](u32x4& v) {                     // DEPTH - 1 younger row loads are outstanding at every wait
+    auto await_rows = [&](u32x4& v) __attribute__((always_inline)) {                     // DEPTH - 1 younger row loads are outstanding at every wait
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
         asm volatile("" : "+v"(v));
     };
@@ -811,7 +823,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     // thresholds [256 wave, 256 wave + 256) are this wave's to keep fresh, four per lane.  The lane number is RECOMPUTED at
     // each use (mbcnt of a laundered zero), or hipcc keeps a 64-bit global address and an LDS address alive through the
     // group loop for two instructions per look -- registers the rare path needs (168 with them: one spilled)
-    auto fresh_index = [&]() {
+    auto fresh_index = [&]() __attribute__((always_inline)) {
         uint32_t z = 0;
         asm volatile("" : "+v"(z));
         return wave_s * 256 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) * 4;
@@ -825,8 +837,72 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     const uint32_t slices = groups * 32 * 4 / 64, nwaves = gridDim.x * (MBLOCK / 64);
     const uint32_t gw = blockIdx.x * (MBLOCK / 64) + wave_s;
     uint32_t trip = 0;
-    // one step over the rows expanded in a[]
-    auto one_step = [&]() {
+    Acc accX, accY;
+    auto all_groups = [&]() __attribute__((always_inline)) {
+        // two B buffers and two accumulator sets: the fragment of group g + 2 is requested while group g + 1 multiplies
+        // (any number of groups: pairs of stages while at least three groups remain, then one stage + the last fold for an even
+        //  rest or the last fold alone for an odd one -- 17..32 queries are ONE group, not one and a padding group)
+        v4i by = lbl[0], bx = lbl[groups > 1 ? 64 : 0];
+        uint32_t thrY = lt[0], thrX = lt[groups > 1 ? 32 : 0];
+        uint32_t mY, mX;
+        first_group(accY, by);
+        uint32_t g = 0;
+#pragma unroll 1
+        for (; g + 2 < groups; g += 2) {
+            by = lbl[(g + 2) * 64];                       // consumed by the stage before
+            const uint32_t thrYn = lt[(g + 2) * 32];
+            if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); __builtin_expect(mk != 0, 0)) save_hits(accY, mk, thrY, g, step);
+            thrY = thrYn;
+            const uint32_t g3 = g + 3 < groups ? g + 3 : g + 2;       // (an odd count has no group g + 3: nothing is multiplied with it)
+            bx = lbl[g3 * 64];
+            const uint32_t thrXn = lt[g3 * 32];
+            if (const uint64_t mk = stage(accY, accX, by, thrX, mX); __builtin_expect(mk != 0, 0)) save_hits(accX, mk, thrX, g + 1, step);
+            thrX = thrXn;
+        }
+        if (g + 1 < groups) {
+            if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
+            if (const uint64_t mk = last_fold(accX, thrX, mX); mk != 0) save_hits(accX, mk, thrX, g + 1, step);
+        } else {
+            if (const uint64_t mk = last_fold(accY, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
+        }
+    };
+    // FEW GROUPS.  With one or two groups a step has nothing of its own to hide behind: the first group's MFMAs and the last
+    // group's fold stood alone (128 + 12 idle cycles and ~80 per 1 KB of rows and wave).  Here the accumulators live ACROSS
+    // steps: a stage multiplies this step's rows while it folds what the previous stage left -- for one group the previous
+    // STEP's products (the two accumulator sets trade roles from step to step: the unrolled DEPTH loop makes that static), for
+    // two groups (s, g0) beside the fold of (s - 1, g1) and (s, g1) beside the fold of (s, g0).  The fragments stay in
+    // registers.  A stage's candidates are processed at once (the ring then never mixes steps); `have`: something to fold.
+    v4i fb[G > 0 ? G : 1];
+    bool have = false;
+    if constexpr (G > 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) fb[g] = lbl[g * 64];
+    }
+    auto few_step = [&](Acc& nw, Acc& od, uint64_t prev) __attribute__((always_inline)) {      // prev: the step before `step`
+        uint32_t m;
+        if constexpr (G == 1) {
+            const uint32_t t0 = lt[0];
+            const uint64_t mk = stage(nw, od, fb[0], t0, m);
+            if (__builtin_expect(have && mk != 0, 0)) { save_hits(od, mk, t0, 0, prev); process_ring(prev); }
+        } else {
+            const uint32_t t0 = lt[0], t1 = lt[32];
+            uint64_t mk = stage(nw, od, fb[0], t1, m);                     // (s, g0) beside the fold of (s - 1, g1)
+            if (__builtin_expect(have && mk != 0, 0)) { save_hits(od, mk, t1, 1, prev); process_ring(prev); }
+            mk = stage(od, nw, fb[G - 1], t0, m);                          // (s, g1) beside the fold of (s, g0)
+            if (__builtin_expect(mk != 0, 0)) { save_hits(nw, mk, t0, 0, step); process_ring(step); }
+        }
+        have = true;
+    };
+    auto few_flush = [&](Acc& od, uint64_t prev) __attribute__((always_inline)) {        // the fold of the last products: those of step `prev`
+        if (have) {
+            uint32_t m;
+            const uint32_t t = lt[(G > 0 ? G - 1 : 0) * 32];
+            if (const uint64_t mk = last_fold(od, t, m); mk != 0) { save_hits(od, mk, t, G > 0 ? G - 1 : 0, prev); process_ring(prev); }
+            have = false;
+        }
+    };
+    // one step over the rows expanded in a[]: `body` multiplies and folds
+    auto one_step = [&](auto&& body) __attribute__((always_inline)) {
         uint32_t fresh[4] = {0u, 0u, 0u, 0u};
         const bool look = trip < 4 || (trip & refresh_mask) == 0;
         const bool refresh_now = refresh && look;
@@ -850,33 +926,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                 }
             }
         }
-        // two B buffers and two accumulator sets: the fragment of group g + 2 is requested while group g + 1 multiplies
-        // (any number of groups: pairs of stages while at least three groups remain, then one stage + the last fold for an even
-        //  rest or the last fold alone for an odd one -- 17..32 queries are ONE group, not one and a padding group)
-        v4i by = lbl[0], bx = lbl[groups > 1 ? 64 : 0];
-        uint32_t thrY = lt[0], thrX = lt[groups > 1 ? 32 : 0];
-        Acc accY, accX;
-        uint32_t mY, mX;
-        first_group(accY, by);
-        uint32_t g = 0;
-#pragma unroll 1
-        for (; g + 2 < groups; g += 2) {
-            by = lbl[(g + 2) * 64];                       // consumed by the stage before
-            const uint32_t thrYn = lt[(g + 2) * 32];
-            if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); __builtin_expect(mk != 0, 0)) save_hits(accY, mk, thrY, g, step);
-            thrY = thrYn;
-            const uint32_t g3 = g + 3 < groups ? g + 3 : g + 2;       // (an odd count has no group g + 3: nothing is multiplied with it)
-            bx = lbl[g3 * 64];
-            const uint32_t thrXn = lt[g3 * 32];
-            if (const uint64_t mk = stage(accY, accX, by, thrX, mX); __builtin_expect(mk != 0, 0)) save_hits(accX, mk, thrX, g + 1, step);
-            thrX = thrXn;
-        }
-        if (g + 1 < groups) {
-            if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
-            if (const uint64_t mk = last_fold(accX, thrX, mX); mk != 0) save_hits(accX, mk, thrX, g + 1, step);
-        } else {
-            if (const uint64_t mk = last_fold(accY, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
-        }
+        body();
         // what the PREVIOUS step's appends returned (issued a whole step ago: no wait), then this step's blocks
         if constexpr (MODE == MODE_SELF) pend_complete();
         if (rcount) process_ring(step);
@@ -893,50 +943,72 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
         while (step < nsteps) {
             expand(x);
             x = load_rows(step + stride < nsteps ? step + stride : step);        // in flight during this step
-            one_step();
+            one_step(all_groups);
             step += stride;
             ++trip;
         }
     } else {
         const uint64_t nfull = p.n_rows / (32 * MT);          // whole steps: [first, nfull); a partial last step is loaded the slow way
+        const uint64_t leap = stride * STRETCH;               // from a wave's stretch of steps to its next one
+        constexpr int HOP = STRETCH == 1 ? 0 : 1;             // (experiment switch ISK_PACK_STRETCH = 0: substep d is step base + d * stride)
         u32x4 x[DEPTH];
-        if (step < nfull) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) issue_rows(x[d], step + d * stride < nfull ? step + d * stride : step);
-            while (step < nfull) {
+        for (int d = 0; d < DEPTH; ++d) x[d] = u32x4{0u, 0u, 0u, 0u};
+        if (step < nfull) {
+            uint64_t base = step, last = step;
+            uint32_t last_d = 0;
+            bool more = true;
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) issue_rows(x[d], base + (HOP ? d : d * stride) < nfull ? base + (HOP ? d : d * stride) : base);
+            while (more) {
 #pragma unroll
                 for (int d = 0; d < DEPTH; ++d) {
-                    if (step >= nfull) break;
+                    step = base + (HOP ? d : d * stride);
+                    if (step >= nfull) { more = false; break; }
+                    const uint64_t prev = HOP ? (d ? step - 1 : step - leap + (DEPTH - 1)) : step - stride;
+                    const uint64_t ahead = HOP ? leap : stride * DEPTH;
                     await_rows(x[d]);
                     expand(x[d]);
-                    issue_rows(x[d], step + DEPTH * stride < nfull ? step + DEPTH * stride : step);     // (past the end: a re-read nobody uses)
-                    one_step();
-                    step += stride;
+                    issue_rows(x[d], step + ahead < nfull ? step + ahead : base);   // (past the end: a re-read nobody uses)
+                    if constexpr (G == 0) one_step(all_groups);
+                    else if constexpr (G == 1 && (DEPTH & 1) == 0) {
+                        if (d & 1) one_step([&]() __attribute__((always_inline)) { few_step(accY, accX, prev); });
+                        else one_step([&]() __attribute__((always_inline)) { few_step(accX, accY, prev); });
+                        last_d = d;
+                    } else one_step([&]() __attribute__((always_inline)) { few_step(accX, accY, prev); });
+                    last = step;
                     ++trip;
                 }
+                if (more) { base += HOP ? leap : stride * DEPTH; step = base; }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (G == 1) {
+                if (last_d & 1) few_flush(accY, last);
+                else few_flush(accX, last);
+            } else if constexpr (G > 1) few_flush(accY, last);
         }
         if (step < nsteps) {                                  // == nfull: this wave owns the partial step
             expand(load_rows(step));
-            one_step();
+            one_step(all_groups);
         }
     }
     if constexpr (MODE == MODE_SELF) pend_complete();
 }
 
-template <int DEPTH>
+template <int DEPTH, int G>
 static void launch_pack_depth(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
-    if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_pack_kernel<MODE_COLLECT, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
-    else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_pack_kernel<MODE_STRETCH, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
-    else if (mode == MODE_SELF) hipLaunchKernelGGL((mfma_pack_kernel<MODE_SELF, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
-    else hipLaunchKernelGGL((mfma_pack_kernel<MODE_BOTH, DEPTH>), grid, dim3(MBLOCK), lds, st, p, groups);
+    if (mode == MODE_COLLECT) hipLaunchKernelGGL((mfma_pack_kernel<MODE_COLLECT, DEPTH, G>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_STRETCH) hipLaunchKernelGGL((mfma_pack_kernel<MODE_STRETCH, DEPTH, G>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else if (mode == MODE_SELF) hipLaunchKernelGGL((mfma_pack_kernel<MODE_SELF, DEPTH, G>), grid, dim3(MBLOCK), lds, st, p, groups);
+    else hipLaunchKernelGGL((mfma_pack_kernel<MODE_BOTH, DEPTH, G>), grid, dim3(MBLOCK), lds, st, p, groups);
 }
 
 static int launch_pack(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
     if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
-    if (groups <= PK_DEEP_GROUPS) launch_pack_depth<4>(mode, grid, lds, st, p, groups);
-    else launch_pack_depth<1>(mode, grid, lds, st, p, groups);
+    if (groups == 1) launch_pack_depth<4, 1>(mode, grid, lds, st, p, groups);
+    else if (groups == 2) launch_pack_depth<4, 2>(mode, grid, lds, st, p, groups);
+    else if (groups <= PK_DEEP_GROUPS) launch_pack_depth<4, 0>(mode, grid, lds, st, p, groups);
+    else launch_pack_depth<1, 0>(mode, grid, lds, st, p, groups);
     return 0;
 }
 
