@@ -535,7 +535,8 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 #define ISK_PACK_STRETCH 1
 #endif
 constexpr int PK_TILES = 4;                                             // row tiles per wave and step
-constexpr uint32_t PK_DEEP_GROUPS = 6;                                  // chunks of up to this many groups (192 queries) keep four steps of rows in flight
+constexpr uint32_t PK_DEEP_GROUPS = 4;                                  // chunks of up to this many groups (128 queries): one instantiation per count,
+                                                                        // four steps of rows in flight, accumulators carried across steps (five and six fit 168 registers no more)
 __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const h2 x = __builtin_bit_cast(h2, a), y = __builtin_bit_cast(h2, b), z = __builtin_bit_cast(h2, c);
@@ -872,24 +873,37 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     // STEP's products (the two accumulator sets trade roles from step to step: the unrolled DEPTH loop makes that static), for
     // two groups (s, g0) beside the fold of (s - 1, g1) and (s, g1) beside the fold of (s, g0).  The fragments stay in
     // registers.  A stage's candidates are processed at once (the ring then never mixes steps); `have`: something to fold.
-    v4i fb[G > 0 ? G : 1];
+    constexpr int FB = G == 1 || G == 2 ? G : 1;          // one or two groups keep their fragments in registers
+    v4i fb[FB];
     bool have = false;
-    if constexpr (G > 0) {
+    if constexpr (G == 1 || G == 2) {
 #pragma unroll
         for (int g = 0; g < G; ++g) fb[g] = lbl[g * 64];
     }
-    auto few_step = [&](Acc& nw, Acc& od, uint64_t prev) __attribute__((always_inline)) {      // prev: the step before `step`
+    // P receives the even groups, Q the odd ones; on entry Q holds the previous step's last group.  An even G leaves its last
+    // group in Q again; an odd G leaves it in P: the caller swaps the sets from step to step.
+    auto few_step = [&](Acc& P, Acc& Q, uint64_t prev) __attribute__((always_inline)) {      // prev: the step before `step`
         uint32_t m;
-        if constexpr (G == 1) {
-            const uint32_t t0 = lt[0];
-            const uint64_t mk = stage(nw, od, fb[0], t0, m);
-            if (__builtin_expect(have && mk != 0, 0)) { save_hits(od, mk, t0, 0, prev); process_ring(prev); }
-        } else {
-            const uint32_t t0 = lt[0], t1 = lt[32];
-            uint64_t mk = stage(nw, od, fb[0], t1, m);                     // (s, g0) beside the fold of (s - 1, g1)
-            if (__builtin_expect(have && mk != 0, 0)) { save_hits(od, mk, t1, 1, prev); process_ring(prev); }
-            mk = stage(od, nw, fb[G - 1], t0, m);                          // (s, g1) beside the fold of (s, g0)
-            if (__builtin_expect(mk != 0, 0)) { save_hits(nw, mk, t0, 0, step); process_ring(step); }
+        v4i bcur;
+        if constexpr (G == 1 || G == 2) bcur = fb[0];
+        else bcur = lbl[0];
+#pragma unroll
+        for (int g = 0; g < (G > 0 ? G : 1); ++g) {
+            v4i bnext = bcur;
+            if (g + 1 < G) {
+                if constexpr (G == 2) bnext = fb[FB - 1];
+                else bnext = lbl[(g + 1) * 64];                             // requested while group g multiplies
+            }
+            Acc& nw = (g & 1) ? Q : P;
+            Acc& od = (g & 1) ? P : Q;
+            const uint32_t t = lt[(g == 0 ? G - 1 : g - 1) * 32];            // the threshold of the group being FOLDED
+            const uint64_t mk = stage(nw, od, bcur, t, m);
+            if (g == 0) {
+                if (__builtin_expect(have && mk != 0, 0)) { save_hits(od, mk, t, G - 1, prev); process_ring(prev); }
+            } else {
+                if (__builtin_expect(mk != 0, 0)) { save_hits(od, mk, t, g - 1, step); process_ring(step); }
+            }
+            bcur = bnext;
         }
         have = true;
     };
@@ -971,7 +985,8 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                     expand(x[d]);
                     issue_rows(x[d], step + ahead < nfull ? step + ahead : base);   // (past the end: a re-read nobody uses)
                     if constexpr (G == 0) one_step(all_groups);
-                    else if constexpr (G == 1 && (DEPTH & 1) == 0) {
+                    else if constexpr ((G & 1) != 0) {
+                        static_assert((DEPTH & 1) == 0, "the accumulator roles of an odd group count alternate with d");
                         if (d & 1) one_step([&]() __attribute__((always_inline)) { few_step(accY, accX, prev); });
                         else one_step([&]() __attribute__((always_inline)) { few_step(accX, accY, prev); });
                         last_d = d;
@@ -982,10 +997,10 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                 if (more) { base += HOP ? leap : stride * DEPTH; step = base; }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (G == 1) {
+            if constexpr ((G & 1) != 0) {                     // the last group waits in P of the last call
                 if (last_d & 1) few_flush(accY, last);
                 else few_flush(accX, last);
-            } else if constexpr (G > 1) few_flush(accY, last);
+            } else if constexpr (G > 1) few_flush(accY, last);   // ... in Q
         }
         if (step < nsteps) {                                  // == nfull: this wave owns the partial step
             expand(load_rows(step));
@@ -1005,10 +1020,14 @@ static void launch_pack_depth(int mode, dim3 grid, size_t lds, hipStream_t st, c
 
 static int launch_pack(int mode, dim3 grid, size_t lds, hipStream_t st, const ScanParams& p, uint32_t groups) {
     if (lds > (size_t)MFMA_MAX_LDS) return (int)hipErrorInvalidValue;
-    if (groups == 1) launch_pack_depth<4, 1>(mode, grid, lds, st, p, groups);
-    else if (groups == 2) launch_pack_depth<4, 2>(mode, grid, lds, st, p, groups);
-    else if (groups <= PK_DEEP_GROUPS) launch_pack_depth<4, 0>(mode, grid, lds, st, p, groups);
-    else launch_pack_depth<1, 0>(mode, grid, lds, st, p, groups);
+    static_assert(PK_DEEP_GROUPS == 4, "one case per count");
+    switch (groups) {           // up to PK_DEEP_GROUPS groups: one instantiation per count (a step's stages are straight-line code)
+        case 1: launch_pack_depth<4, 1>(mode, grid, lds, st, p, groups); break;
+        case 2: launch_pack_depth<4, 2>(mode, grid, lds, st, p, groups); break;
+        case 3: launch_pack_depth<4, 3>(mode, grid, lds, st, p, groups); break;
+        case 4: launch_pack_depth<4, 4>(mode, grid, lds, st, p, groups); break;
+        default: launch_pack_depth<1, 0>(mode, grid, lds, st, p, groups);
+    }
     return 0;
 }
 
