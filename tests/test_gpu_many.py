@@ -190,3 +190,53 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
             hip_engine.set_option("speculate", 1)
     finally:
         t.drop()
+
+
+@pytest.mark.parametrize("nq", [17, 32, 64, 100, 128])
+def test_matrix_core_batches_speculate_too(hip_engine, nq):
+    """
+    Up to ``spec_max_queries`` (128) queries: the speculative pass of a batch of 17 or more runs on the packed matrix-core kernel
+    in collect mode (chunks of one to four groups).  Hit, miss (one query far from everything the others are near) and the
+    batch one above the limit (ordinary path), each against the oracle.
+    """
+    from oracle import oracle_topk
+
+    rng = np.random.default_rng(1000 + nq)
+    n, k = 300_000, 10
+    words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
+    near = words[rng.integers(0, n, size=4 * nq), 0] ^ (np.uint64(1) << rng.integers(0, 64, size=4 * nq).astype(np.uint64))
+    # k + 2 copies near every `near` query: their k-th distance is <= 2
+    extra = np.repeat(near, k + 2) ^ (np.uint64(1) << rng.integers(0, 64, size=4 * nq * (k + 2)).astype(np.uint64))
+    words = np.concatenate([words, extra.reshape(-1, 1)])
+    keys = np.concatenate([keys, np.arange(len(extra), dtype=np.uint64) + np.uint64(n + 1)])
+    t = hip_engine.open_table(0, 1, 8)
+    try:
+        t.add(keys, words)
+
+        def ask(q):
+            q = np.ascontiguousarray(np.asarray(q, dtype=np.uint64).reshape(-1, 1))
+            before = hip_engine.stats()
+            got = t.search(q, None, k)
+            after = hip_engine.stats()
+            exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+            for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                np.testing.assert_array_equal(g, e, err_msg=name)
+            return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"], after["mfma_pack_launches"] - before["mfma_pack_launches"]
+
+        random_q = rng.integers(1, 2**64, size=3 * nq, dtype=np.uint64)
+        assert ask(random_q[:nq])[:2] == (0, 0)                      # the first search of the segment: nothing to go by
+        hits, misses, packed = ask(random_q[nq : 2 * nq])
+        assert (hits, misses) == (1, 0) and packed >= 1              # random queries after random queries: one packed collect pass
+        assert ask(near[:nq])[:2] == (1, 0)                          # all within the radius, far below it
+        mixed = near[nq : 2 * nq].copy()
+        mixed[nq // 2] = random_q[2 * nq]                            # ended at <= 2 + 2: one random query finds nothing there
+        assert ask(mixed)[:2] == (0, 1)
+        assert ask(random_q[2 * nq : 3 * nq])[:2] == (1, 0)          # the miss re-seeded the radius
+        hip_engine.set_option("spec_max_queries", nq - 1)
+        try:
+            assert ask(random_q[:nq])[:2] == (0, 0)
+        finally:
+            hip_engine.set_option("spec_max_queries", 128)
+    finally:
+        t.drop()

@@ -67,8 +67,12 @@ def forced(hip_engine):
     hip_engine.set_option("mfma_min_rows", 65536)
 
 
+# (65..128 queries: chunks of three and four groups, their own instantiations; 160: five groups, the general loop with an odd count;
+#  2 M rows: every wave takes more than one stretch of four steps, so the accumulators carried across steps change hands)
 @pytest.mark.parametrize("n,k,nq,nbytes", [(127, 5, 20, 8), (129, 10, 33, 8), (70_003, 10, 64, 8), (300_001, 100, 40, 8), (200_000, 10, 1024, 8),
-                                           (50_000, 10, 48, 1), (50_000, 10, 48, 3), (50_000, 10, 48, 5), (90_001, 20, 48, 7)])
+                                           (50_000, 10, 48, 1), (50_000, 10, 48, 3), (50_000, 10, 48, 5), (90_001, 20, 48, 7),
+                                           (150_001, 10, 70, 8), (150_001, 10, 96, 8), (150_001, 10, 128, 8), (100_003, 10, 160, 8),
+                                           (2_000_003, 10, 32, 8), (2_000_003, 10, 64, 8), (2_000_003, 10, 96, 8), (2_000_003, 10, 128, 8)])
 def test_packed_kernel_vs_oracle_and_unpacked(forced, n, k, nq, nbytes):
     rng = np.random.default_rng(4242 + n + nbytes)
     t, keys, words, mask = _table(forced, rng, n, nbytes)
@@ -120,14 +124,14 @@ def test_an_all_zero_64_bit_query_keeps_the_batch_off_the_packed_kernel(forced):
         t.drop()
 
 
-@pytest.mark.parametrize("radius", [0, 1, 12, 31, 32, 63, 64])
-def test_range_limited_searches_on_the_packed_kernel(forced, radius):
+@pytest.mark.parametrize("radius,nq", [(0, 24), (1, 24), (12, 24), (31, 24), (32, 24), (63, 24), (64, 24), (1, 50), (12, 80), (14, 128), (32, 100), (12, 200)])
+def test_range_limited_searches_on_the_packed_kernel(forced, radius, nq):
     """Collect mode under a GIVEN threshold, up to the radius that admits every row (thr = 64 - popc(q): both ends of a half)."""
-    rng = np.random.default_rng(99 + radius)
+    rng = np.random.default_rng(99 + radius + nq)
     n = 3_000 if radius >= 31 else 150_000
     t, keys, words, mask = _table(forced, rng, n)
     try:
-        q = _queries(rng, words, 24, mask, zero_query=False)
+        q = _queries(rng, words, nq, mask, zero_query=False)
         k = 4096 if radius >= 31 else 64
         before = forced.stats()
         gk, gh, gp, gc = t.search_within(q, None, k, radius)
