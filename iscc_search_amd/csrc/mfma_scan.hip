@@ -531,6 +531,9 @@ __global__ __launch_bounds__(MBLOCK, mfma_min_waves<W>()) void mfma_scan_kernel(
 //
 // d2 = +64 (query == 0 against a row of all ones) would carry into the exponent and halve the resolution of the low half:
 // the host routes a batch holding an all-zero 64-bit query to the kernel above (Batch::begin, isccsearch.hip).
+#ifndef ISK_PACK_CARRY
+#define ISK_PACK_CARRY 1       // experiment switch: 0 = the general loop never carries its accumulators across steps
+#endif
 #ifndef ISK_PACK_STRETCH
 #define ISK_PACK_STRETCH 1
 #endif
@@ -867,6 +870,40 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
             if (const uint64_t mk = last_fold(accY, thrY, mY); mk != 0) save_hits(accY, mk, thrY, g, step);
         }
     };
+    // The general loop with the same carry across steps, for EVEN group counts (an odd count would trade the roles of the two
+    // accumulator sets from step to step: two copies of the loop, which do not fit 168 registers): the step's first stage
+    // multiplies group 0 into accY while it folds what the PREVIOUS step left in accX (its last group) -- `first_group` and
+    // `last_fold` stood alone for 128 + 12 and ~80 cycles per step and wave, 5 % of a 32-group step.
+    bool carried = false;                                 // accX holds the previous step's last group
+    auto even_groups = [&](uint64_t prev) __attribute__((always_inline)) {
+        v4i by = lbl[0], bx = lbl[64];
+        uint32_t thrY = lt[0], thrX = lt[32];
+        const uint32_t thrL = lt[(groups - 1) * 32];
+        uint32_t mY, mX;
+        if (const uint64_t mk = stage(accY, accX, by, thrL, mX); __builtin_expect(carried && mk != 0, 0)) { save_hits(accX, mk, thrL, groups - 1, prev); process_ring(prev); }
+        uint32_t g = 0;
+#pragma unroll 1
+        for (; g + 2 < groups; g += 2) {
+            by = lbl[(g + 2) * 64];                       // consumed by the stage before
+            const uint32_t thrYn = lt[(g + 2) * 32];
+            if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); __builtin_expect(mk != 0, 0)) save_hits(accY, mk, thrY, g, step);
+            thrY = thrYn;
+            bx = lbl[(g + 3) * 64];
+            const uint32_t thrXn = lt[(g + 3) * 32];
+            if (const uint64_t mk = stage(accY, accX, by, thrX, mX); __builtin_expect(mk != 0, 0)) save_hits(accX, mk, thrX, g + 1, step);
+            thrX = thrXn;
+        }
+        if (const uint64_t mk = stage(accX, accY, bx, thrY, mY); __builtin_expect(mk != 0, 0)) save_hits(accY, mk, thrY, g, step);
+        carried = true;
+    };
+    auto even_flush = [&](uint64_t prev) __attribute__((always_inline)) {
+        if (carried) {
+            uint32_t m;
+            const uint32_t t = lt[(groups - 1) * 32];
+            if (const uint64_t mk = last_fold(accX, t, m); mk != 0) { save_hits(accX, mk, t, groups - 1, prev); process_ring(prev); }
+            carried = false;
+        }
+    };
     // FEW GROUPS.  With one or two groups a step has nothing of its own to hide behind: the first group's MFMAs and the last
     // group's fold stood alone (128 + 12 idle cycles and ~80 per 1 KB of rows and wave).  Here the accumulators live ACROSS
     // steps: a stage multiplies this step's rows while it folds what the previous stage left -- for one group the previous
@@ -954,12 +991,23 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     };
     if constexpr (DEPTH == 1) {
         u32x4 x = load_rows(step);
-        while (step < nsteps) {
-            expand(x);
-            x = load_rows(step + stride < nsteps ? step + stride : step);        // in flight during this step
-            one_step(all_groups);
-            step += stride;
-            ++trip;
+        if ((groups & 1) || !ISK_PACK_CARRY) {
+            while (step < nsteps) {
+                expand(x);
+                x = load_rows(step + stride < nsteps ? step + stride : step);    // in flight during this step
+                one_step(all_groups);
+                step += stride;
+                ++trip;
+            }
+        } else {
+            while (step < nsteps) {
+                expand(x);
+                x = load_rows(step + stride < nsteps ? step + stride : step);
+                one_step([&]() __attribute__((always_inline)) { even_groups(step - stride); });
+                step += stride;
+                ++trip;
+            }
+            even_flush(step - stride);
         }
     } else {
         const uint64_t nfull = p.n_rows / (32 * MT);          // whole steps: [first, nfull); a partial last step is loaded the slow way
