@@ -115,7 +115,7 @@ const char* isccsearch_last_error(void);
  * bootstrapped from max("self_boot_rows" (65 536), "self_boot_per_k" (1 024) x k) rows and looking at the live thresholds every "self_refresh_steps" (1) steps,
  * instead of threshold levels growing by "mfma_level_growth" (4)); "mfma_pack" (0|1, default 1: 64-bit codes run the packed
  * form of that kernel -- two row tiles per accumulator, v_pk_minimum3_f16 fold -- unless the batch holds an all-zero query);
- * "speculate" (0|1, default 1: a batch of fewer than "mfma_min_queries" queries over a one-segment table is first tried as ONE
+ * "speculate" (0|1, default 1: a batch of up to "spec_max_queries" (128) queries over a one-segment table is first tried as ONE
  * range-limited pass under the k-th distance the previous such search ended at + 2, and verified: exact either way);
  * "candidate_cap" (16 384: floor of the per-query candidate
  * buffer, in entries); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
