@@ -64,9 +64,9 @@ for regime in DOMINANT:
 ROWS, NQ = 100_000_000, 1024
 fetch = {"commit": commit, "command": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extra-legs --steps 3 --warmup 1 [--opt mfma=0] [--opt stretch_mb=0]",
          "correction": "gfx950 FETCH_SIZE reports exactly half of a 16 B/lane coalesced stream (MI355X_MICROARCH.md, HBM): bytes = FETCH_SIZE(KB) x 1024 x 2 for the "
-                       "XOR + popcount kernel's dwordx4 loads.  The matrix-core kernel loads 4 B per lane (one dword of a row per lane); that width is uncalibrated in the "
-                       "guide, so both the raw and the x2 figure are given and `corrected_bytes_per_launch` uses x2 as the upper bound.  FETCH_SIZE counts what the L2s "
-                       "fetch from the fabric: Infinity-Cache hits are included.",
+                       "dwordx4 loads of the XOR + popcount kernel and -- since the packed matrix-core kernel reads its rows with one dwordx4 per lane and step too "
+                       "(round 3; 4 B per lane before, with the same counter value) -- of both kernels: raw and x2 figure are given, `corrected_bytes_per_launch` is x2.  "
+                       "FETCH_SIZE counts what the L2s fetch from the fabric: Infinity-Cache hits are included.",
          "regimes": {}}
 for regime, key in (("mfma", "mfma"), ("valu", "valu_blocked"), ("streaming", "valu_streaming")):
     cc = one(f"prof_fetch_{regime}/**/*counter_collection.csv")
