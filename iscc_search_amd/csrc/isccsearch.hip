@@ -168,6 +168,7 @@ struct isccsearch_handle {
     uint64_t mfma_stretch_factor = 3;               // ... times this on the matrix cores, when several CHUNKS of queries share them
     // large batches: the scan as an FP4 matrix-core contraction (mfma_scan.hip) instead of XOR + popcount on the VALU
     bool mfma = true;
+    uint32_t mfma_pack_min_queries = 9;   // 64-bit codes (packed matrix-core kernel): from this many queries (see use_mfma)
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
@@ -471,12 +472,16 @@ struct Batch {
     // the matrix cores (mfma_scan.hip): every block keeps a chunk of up to 1 024 / W expanded queries in LDS and the
     // rows cross the memory system once per chunk; small batches stay on the XOR + popcount kernel, which is
     // HBM-bound up to ~11 queries per pass.  Both append the same candidates under the same thresholds.
-    bool use_mfma(uint64_t rows) const { return h->mfma && nq_pad >= h->mfma_min_queries && rows >= h->mfma_min_rows; }
+    // (64-bit codes on the PACKED kernel win from 9 queries: 9 / 12 / 16 queries over 100 M rows 0.254 / 0.259 / 0.255 ms per step on the
+    //  XOR + popcount kernel -- one pass of 16 -- against 0.206 / 0.203 / 0.197; 8 queries 0.168 against 0.208; longer codes tie at 16)
+    bool use_mfma(const Job& j, uint64_t rows) const {
+        return h->mfma && nq_pad >= (j.pack ? std::min(h->mfma_min_queries, h->mfma_pack_min_queries) : h->mfma_min_queries) && rows >= h->mfma_min_rows;
+    }
     int scan(const Job& j, const isk::ScanParams& sp, int mode, bool sample) {
         const uint64_t rows = sp.n_rows - sp.row_begin;
         // A self-tightening pass is decided once per job (use_mfma over the whole segment) and lives on the matrix cores: EVERY
         // stretch of it runs there, also a short last one -- the XOR + popcount kernels have no MODE_SELF
-        if (use_mfma(rows) || mode == isk::MODE_SELF) {
+        if (use_mfma(j, rows) || mode == isk::MODE_SELF) {
             const uint32_t g = isk::mfma_groups_per_chunk((int)j.W, nq_pad, j.pack);
             const uint32_t chunks = (nq_pad + g * 32 - 1) / (g * 32);
             const uint64_t rps = isk::mfma_rows_per_wave_step((int)j.W, j.pack);
@@ -576,11 +581,11 @@ struct Batch {
             auto collect_from = [&](uint64_t from, bool self = false) -> int {
                 uint64_t stretch = s.n;
                 // (the MFMA kernel reads the rows once per CHUNK of up to 1 024 / W queries: one chunk has nothing to share)
-                const bool shared = use_mfma(s.n - from) ? nq_pad > isk::mfma_groups_per_chunk((int)j.W, nq_pad, j.pack) * 32 : groups > 1;
+                const bool shared = use_mfma(j, s.n - from) ? nq_pad > isk::mfma_groups_per_chunk((int)j.W, nq_pad, j.pack) * 32 : groups > 1;
                 // (matrix-core launches: the chunks' blocks are all resident and walk a stretch in step, so three times the size
                 //  still shares it in the caches and every launch saved is ~30 us of ramp and tail.  Same box, factor 1 / 2 / 3 / 4:
                 //  256-bit 9.31 / 8.90 / 8.79 / 8.72 ms, 128-bit 4.67 / 4.55 / 4.53 / 4.52, 192-bit 7.88 / 7.74 / 7.67 / 7.99)
-                const uint64_t stretch_bytes = use_mfma(s.n - from) ? h->stretch_bytes * h->mfma_stretch_factor : h->stretch_bytes;
+                const uint64_t stretch_bytes = use_mfma(j, s.n - from) ? h->stretch_bytes * h->mfma_stretch_factor : h->stretch_bytes;
                 if (shared && stretch_bytes) stretch = std::max<uint64_t>(tile_rows, stretch_bytes / (8 * j.W) / tile_rows * tile_rows);
                 for (uint64_t a = from; a < s.n;) {
                     const uint64_t b = s.n - a <= stretch + stretch / 4 ? s.n : a + stretch;     // no sliver at the end
@@ -614,7 +619,7 @@ struct Batch {
                     h->stats.scan_passes += groups;
                     h->stats.scan_bytes += rows * 8 * j.W * groups;
                     h->stats.scan_pair_words += rows * (uint64_t)nq * j.W;
-                    if (use_mfma(rows) || self) h->stats.scan_mfma_launches += 1;
+                    if (use_mfma(j, rows) || self) h->stats.scan_mfma_launches += 1;
                     a = b;
                 }
                 return 0;
@@ -642,7 +647,7 @@ struct Batch {
             //    tile could see a new threshold -- before any update reaches them, and fresh thresholds must be read past the
             //    per-XCD L2s (sc1 / glc), where 8 192 waves hammering one line serialise: measured 0.24-0.53 ms for 1-8
             //    queries over 100 M rows against 0.10 ms for the collect pass of the level design.)
-            const bool self = allow_self && h->self_tighten && k <= h->self_max_k && use_mfma(s.n);
+            const bool self = allow_self && h->self_tighten && k <= h->self_max_k && use_mfma(j, s.n);
             used_self = used_self || self;
             // (the single pass appends everything within the bootstrap threshold until the first update arrives -- 3 072 waves x
             //  128 rows at once -- so its sample grows with k (1 024 k rows): 512 k measured 4.39 -> 3.80 ms at k = 256 and 11.9 (list
@@ -689,7 +694,7 @@ struct Batch {
             //    64x when there are so few query groups that launch gaps outweigh candidate handling; less
             //    when k * growth would not fit the candidate buffer).  No row is read twice.
             uint64_t growth = (groups <= 2 && k <= 64) ? std::max<uint64_t>(64, h->level_growth) : h->level_growth;
-            if (use_mfma(s.n) && k <= 64) growth = h->mfma_level_growth;   // matrix-core launches: see the option's comment
+            if (use_mfma(j, s.n) && k <= 64) growth = h->mfma_level_growth;   // matrix-core launches: see the option's comment
             if (k >= 256) growth = std::min<uint64_t>(growth, 2);   // simprint-sized k: candidate handling dominates, +10 % with short levels
             // a stretch `growth` times the rows seen so far brings ~growth * (rows at or under tau) candidates, and the
             // tie class at tau can make that 2.3x k (ratio of consecutive binomial tails): keep it inside the buffer
@@ -715,7 +720,7 @@ struct Batch {
                     if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
                     h->stats.level_launches += 1;
                     h->stats.level_pair_words += (end - done) * (uint64_t)nq * j.W;
-                    if (use_mfma(end - done)) h->stats.level_mfma_launches += 1;
+                    if (use_mfma(j, end - done)) h->stats.level_mfma_launches += 1;
                 }
                 isk::PickParams pp{h->d_ghist.p, h->d_bias.p, nq, (uint32_t)std::min<uint64_t>(k, end), h->d_cnt.p, h->d_cand.p, cap};
                 hipLaunchKernelGGL(isk::pick_kernel, dim3(nq), dim3(isk::BLOCK), 0, h->stream, pp);
@@ -1027,6 +1032,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "fold_tau")) { if (value < 0 || value > 32) return fail(-EINVAL, "fold_tau must be 0..32"); h->fold_tau = (uint32_t)value; return 0; }
     if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
+    if (!strcmp(name, "mfma_pack_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_pack_min_queries must be 1..1024"); h->mfma_pack_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_tighten")) { h->self_tighten = value != 0; return 0; }
     if (!strcmp(name, "boot_multi")) { h->boot_multi = value != 0; return 0; }

@@ -10,8 +10,9 @@ print('%-58s %10.0f q/s  %8.3f ms/step  %-5s frac %.3f  scan %8.3f ms x %-3d fal
 }
 echo "# bench.py --no-cpu-baseline --no-extra-legs --no-other-configs --settle-steps 20 <args>: queries/s, ms per step, bound and fraction of its roofline, ms per scan launch x launches in 20 steps"
 run
-echo "# batch size (100 M x 64-bit, k = 10): <= 16 queries run the XOR + popcount kernel (levels), more the packed matrix-core kernel (one pass)"
-for q in 1 4 8 16 17 32 64 128 256 512; do run --queries $q; done
+echo "# batch size (100 M x 64-bit, k = 10): <= 8 queries run the XOR + popcount kernel, more the packed matrix-core kernel; up to 128 queries one speculative range-limited pass (the ordinary path of the same sizes: --opt speculate=0 below)"
+for q in 1 4 8 9 12 16 17 32 64 96 128 192 256 512; do run --queries $q; done
+for q in 1 8 16 32 64 128; do run --queries $q --opt speculate=0; done
 echo "# k"
 for k in 1 100 256 512 1000; do run --k $k; done
 echo "# code length (Hamming tables of 128 / 192 / 256-bit codes) and config 3 (NPHD table of 256-bit units)"
