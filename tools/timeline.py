@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 Timeline of one search step from a rocprofv3 --kernel-trace CSV: every kernel of the LAST complete step (a step starts
-at boot_kernel / radius_init_kernel) with its duration and the gap to the previous kernel's end.
+at boot_kernel / boot_multi_kernel / radius_init[_inline]_kernel) with its duration and the gap to the previous kernel's end.
 
 usage: timeline.py <..._kernel_trace.csv> [steps back from the last, default 1]
 """
@@ -15,7 +15,7 @@ def main():
     with open(path) as f:
         rows = list(csv.DictReader(f))
     seq = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"]) for r in rows))
-    starts = [i for i, s in enumerate(seq) if "boot_kernel" in s[2] or "boot_multi_kernel" in s[2] or "radius_init_kernel" in s[2]]
+    starts = [i for i, s in enumerate(seq) if "boot_kernel" in s[2] or "boot_multi_kernel" in s[2] or "radius_init_kernel" in s[2] or "radius_init_inline_kernel" in s[2]]
     if len(starts) < back + 1:
         raise SystemExit("not enough steps in the trace")
     a, b = starts[-back - 1], starts[-back]
