@@ -78,8 +78,22 @@ struct Segment {
     uint32_t freq_dup = 0;         // dup_limit it was built with
     void touch() { freq_rows = 0; }
     // small batches (the reference's per-unit call shape): the k-th distance the last search of this segment ended at -- the next
-    // one tries ONE collect pass under it (+ margin) before the bootstrap / level / pick chain (search_locked)
-    uint32_t spec_k = 0, spec_tau = 0;
+    // one tries ONE collect pass under it (+ margin) before the bootstrap / level / pick chain (search_locked).  One hint per
+    // batch-size class (the worst k-th distance of 100 queries lies a bit or two above that of one); a hint decays by one bit per
+    // hit towards what the batches need (a near-duplicate query between two ordinary ones does not pull it down to its own
+    // distance); a miss makes the next `penalty` batches of the class take the ordinary path (1, 3, 7, 15 for misses in a row).
+    struct SpecHint {
+        uint32_t k = 0, tau = 0, skip = 0, penalty = 0;
+        bool ready(uint32_t want_k) {                       // speculate now?
+            if (k != want_k) return false;
+            if (skip) { skip -= 1; return false; }
+            return true;
+        }
+        void hit(uint32_t worst) { penalty = 0; tau = std::min<uint32_t>(std::max<uint32_t>(worst + 2, tau ? tau - 1 : 0), 8 * ISCCSEARCH_MAX_BYTES); }
+        void miss() { penalty = std::min<uint32_t>(2 * penalty + 1, 15); skip = penalty - 1; }      // (the rerun that follows is the first skipped batch)
+        void seed(uint32_t new_k, uint32_t worst) { k = new_k; tau = std::min<uint32_t>(worst + 2, 8 * ISCCSEARCH_MAX_BYTES); }
+    } spec[12];
+    SpecHint& hint(uint32_t nq) { return spec[nq ? 32 - __builtin_clz(nq) : 0]; }      // 1 | 2-3 | 4-7 | ... | 1024
 };
 
 struct Table {
@@ -172,6 +186,7 @@ struct isccsearch_handle {
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
+    bool spec_suppress = false;       // (isccsearch_search_many: the ordinary rerun of a request whose speculative pass just missed)
     int speculate = 1;                // small batches: try one range-limited pass under the previous search's k-th distance first
     uint32_t spec_max_queries = 128;   // ... batches of up to this many queries
     int mfma_pack = 1;                // 64-bit codes on the matrix cores: two row tiles per accumulator, packed f16 fold (mfma_pack_kernel)
@@ -1561,8 +1576,9 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         if (segments == 1)
             for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) if (t.seg[b].n) spec_seg = &t.seg[b];
         const bool small_batch = spec_seg && radius < 0 && !out_freq && one_copy && m <= h->spec_max_queries && k <= spec_seg->n;
-        const bool speculate = small_batch && h->speculate && spec_seg->spec_k == k;
-        if (speculate) batch.radius = (int)spec_seg->spec_tau;
+        const bool speculate = small_batch && h->speculate && !h->spec_suppress && spec_seg->hint(m).ready(k);
+        if (speculate) batch.radius = (int)spec_seg->hint(m).tau;
+        bool spec_ok = false;
         auto copy_results = [&]() -> int {
             if (out_freq) {
                 // only the distinct-asset count of every list leaves the device
@@ -1607,9 +1623,11 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             if (batch.any_flag()) ok = false;
             const uint32_t need = (uint32_t)std::min<uint64_t>(k, spec_seg->n);
             for (uint32_t i = 0; i < m && ok; ++i) ok = p_cnt[i] >= need;
+            spec_ok = ok;
             if (ok) h->stats.spec_hits += 1;
             else {
                 h->stats.spec_misses += 1;
+                spec_seg->hint(m).miss();
                 batch.radius = -1;
                 if ((rc = batch.begin(hq.data()))) return rc;
                 if ((rc = copy_results())) return rc;
@@ -1648,8 +1666,8 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             uint32_t worst = 0;
             for (uint32_t i = 0; i < m; ++i)
                 if (p_cnt[i]) worst = std::max<uint32_t>(worst, p_rec[(size_t)i * k + p_cnt[i] - 1].hamming);
-            spec_seg->spec_k = k;
-            spec_seg->spec_tau = std::min<uint32_t>(worst + 2, 8 * ISCCSEARCH_MAX_BYTES);
+            if (spec_ok) spec_seg->hint(m).hit(worst);
+            else spec_seg->hint(m).seed(k, worst);
         }
         if (out_freq) {
             if (batch.jobs.empty()) for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = 0;
@@ -1862,8 +1880,8 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         // small top-k batches: the speculative single pass of search_locked (see there), verified in pass 3a
         for (uint32_t bb = 1; bb <= ISCCSEARCH_MAX_BYTES; ++bb) if (t.seg[bb].n) sl.seg = &t.seg[bb];
         sl.small = r.max_hamming < 0 && r.nq <= h->spec_max_queries && sl.seg && r.k <= sl.seg->n;
-        sl.spec = sl.small && h->speculate && sl.seg->spec_k == r.k;
-        if (sl.spec) b.radius = (int)sl.seg->spec_tau;
+        sl.spec = sl.small && h->speculate && sl.seg->hint(r.nq).ready(r.k);
+        if (sl.spec) b.radius = (int)sl.seg->hint(r.nq).tau;
         b.pq_off = pq_off;
         b.d_flags = d_cnt + r.nq;
         b.h_flags = p_cnt + r.nq;
@@ -1879,7 +1897,7 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
 
     // pass 3a: hand out EVERY deferred result first.  The ordinary pipeline below stages its own results in p_block
     // from offset 0 (and may reallocate it), so no deferred slice may still be unread when it runs.
-    std::vector<bool> ordinary(n, false);
+    std::vector<bool> ordinary(n, false), respec(n, true);      // respec: the ordinary rerun may itself speculate (not after a miss)
     for (uint32_t i = 0; i < n; ++i) {
         isccsearch_request& r = reqs[i];
         if (r.status || r.nq == 0) continue;
@@ -1894,15 +1912,15 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
             const uint32_t need = (uint32_t)std::min<uint64_t>(r.k, sl.seg->n);
             for (uint32_t q = 0; q < r.nq && ok; ++q) ok = p_cnt[q] >= need;
             if (ok) h->stats.spec_hits += 1;
-            else { h->stats.spec_misses += 1; sl.seg->spec_k = 0; ordinary[i] = true; continue; }      // (the ordinary path re-seeds the radius)
+            else { h->stats.spec_misses += 1; sl.seg->hint(r.nq).miss(); ordinary[i] = true; respec[i] = false; continue; }      // (the ordinary path re-seeds the radius)
         }
         if (!b.jobs.empty() && b.any_flag()) { ordinary[i] = true; continue; }   // rare: exact fallback through the normal path
         if (sl.small && !b.jobs.empty()) {
             uint32_t worst = 0;
             for (uint32_t q = 0; q < r.nq; ++q)
                 if (p_cnt[q]) worst = std::max<uint32_t>(worst, p_rec[(size_t)q * r.k + p_cnt[q] - 1].hamming);
-            sl.seg->spec_k = r.k;
-            sl.seg->spec_tau = std::min<uint32_t>(worst + 2, 8 * ISCCSEARCH_MAX_BYTES);
+            if (sl.spec) sl.seg->hint(r.nq).hit(worst);
+            else sl.seg->hint(r.nq).seed(r.k, worst);
         }
         unpack_records(p_rec, p_cnt, r.nq, r.k, h->tables[r.table]->key_words, nullptr, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count);
     }
@@ -1911,8 +1929,10 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         if (!ordinary[i]) continue;
         isccsearch_request& r = reqs[i];
         if (!deferred[i]) h->stats.searches += 1;
+        h->spec_suppress = !respec[i];
         rc = search_locked(h, r.table, r.nq, r.q_words, r.q_nbytes, r.k, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count,
                            r.max_hamming < 0 ? -1 : r.max_hamming);
+        h->spec_suppress = false;
         if (rc) reject(r, rc);
     }
     return first_error;

@@ -155,19 +155,22 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
                 np.testing.assert_array_equal(g, e, err_msg=name)
             return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"], int(got[1].max())
 
-        random_q = rng.integers(0, 2**64, size=9, dtype=np.uint64)
-        assert ask(random_q[:1])[:2] == (0, 0)                       # nothing to go by yet
-        hits, misses, worst = ask(random_q[1:2])
+        r = rng.integers(0, 2**64, size=16, dtype=np.uint64)
+        assert ask(r[:1])[:2] == (0, 0)                              # nothing to go by yet
+        hits, misses, worst = ask(r[1:2])
         assert (hits, misses) == (1, 0) and worst >= 10              # the previous search's k-th distance + 2 holds this one's
-        assert ask(random_q[2:6])[:2] == (1, 0)                      # a batch of four
+        assert ask(r[2:6])[:2] == (0, 0)                             # a batch of four: another size class, its own hint
+        assert ask(r[2:6])[:2] == (1, 0)
+        assert ask([small])[:2] == (1, 0)                            # 3 000 near-duplicates inside a random query's radius: they fit
+        assert ask(r[6:7])[:2] == (1, 0)                             # ... and the hint decayed by ONE bit, not to their distance
         assert ask([big])[:2] == (0, 1)                              # 40 000 rows within the radius: the list overflows -> ordinary path
-        assert ask(random_q[6:7])[:2] == (0, 1)                      # `big` ended at distance 1: radius 3 holds nothing of a random query
-        assert ask([small])[:2] == (1, 0)                            # 3 000 rows within the radius: fits, k of them at distance 1
-        assert ask([small ^ np.uint64(3)])[:2] == (1, 0)             # radius 3: the same 3 000 rows at distance 1 or 3
-        assert ask(random_q[7:8])[:2] == (0, 1)                      # far from the cluster again
-        assert ask(random_q[8:9])[:2] == (1, 0)
+        assert ask(r[7:8])[:2] == (0, 1)                             # `big` ended at distance 1: radius 3 holds nothing of a random query
+        assert ask(r[8:9])[:2] == (0, 0)                             # two misses in a row: the next two batches do not speculate
+        assert ask(r[9:10])[:2] == (0, 0)
+        assert ask(r[10:11])[:2] == (1, 0)
+        assert ask([small ^ np.uint64(3)])[:2] == (1, 0)             # the same 3 000 rows at distance 1 or 3
         # the per-unit searches of one search_assets request (isccsearch_search_many) speculate the same way, verified after their
-        # one synchronisation: two requests hit, then a far query after a clustered one misses and is answered by the ordinary path
+        # one synchronisation; a request whose pass missed is rerun on the ordinary path (which does not speculate again)
         def ask_many(qs):
             reqs = [(t, np.asarray([q], dtype=np.uint64).reshape(1, 1), None, k, None) for q in qs]
             before = hip_engine.stats()
@@ -179,13 +182,16 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
                     np.testing.assert_array_equal(g, e, err_msg=name)
             return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"]
 
-        assert ask_many(random_q[:2]) == (2, 0)
+        assert ask_many(r[:2]) == (2, 0)
         assert ask_many([small]) == (1, 0)
-        assert ask_many(random_q[2:4]) == (1, 2)                     # both were enqueued under radius 3; the second one's rerun already profits from the first one's
-        assert ask_many(random_q[4:6]) == (2, 0)
+        assert ask_many([big]) == (0, 1)                             # overflow; the rerun seeds radius 3
+        assert ask_many(r[2:4]) == (0, 2)                            # both were enqueued under radius 3: misses two and three in a row
+        assert ask_many(r[4:8]) == (0, 0)                            # ... six batches of back-off, four of them here
+        assert ask_many(r[8:10]) == (0, 0)
+        assert ask_many(r[10:12]) == (2, 0)
         hip_engine.set_option("speculate", 0)
         try:
-            assert ask(random_q[:3])[:2] == (0, 0)
+            assert ask(r[:3])[:2] == (0, 0)
         finally:
             hip_engine.set_option("speculate", 1)
     finally:
@@ -195,8 +201,8 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
 @pytest.mark.parametrize("nq", [17, 32, 64, 100, 128])
 def test_matrix_core_batches_speculate_too(hip_engine, nq):
     """
-    Up to ``spec_max_queries`` (128) queries: the speculative pass of a batch of 17 or more runs on the packed matrix-core kernel
-    in collect mode (chunks of one to four groups).  Hit, miss (one query far from everything the others are near) and the
+    Up to ``spec_max_queries`` (128) queries: the speculative pass of a batch of 9 or more runs on the packed matrix-core kernel
+    in collect mode (chunks of one to four groups).  Hit, miss (one query inside a cluster that overflows its list) and the
     batch one above the limit (ordinary path), each against the oracle.
     """
     from oracle import oracle_topk
@@ -208,8 +214,11 @@ def test_matrix_core_batches_speculate_too(hip_engine, nq):
     near = words[rng.integers(0, n, size=4 * nq), 0] ^ (np.uint64(1) << rng.integers(0, 64, size=4 * nq).astype(np.uint64))
     # k + 2 copies near every `near` query: their k-th distance is <= 2
     extra = np.repeat(near, k + 2) ^ (np.uint64(1) << rng.integers(0, 64, size=4 * nq * (k + 2)).astype(np.uint64))
-    words = np.concatenate([words, extra.reshape(-1, 1)])
-    keys = np.concatenate([keys, np.arange(len(extra), dtype=np.uint64) + np.uint64(n + 1)])
+    # and a cluster of 30 000 rows one bit off `centre`: more than a candidate list holds
+    centre = np.uint64(0x5A5A5A5A12345678)
+    cluster = centre ^ (np.uint64(1) << rng.integers(0, 64, size=30_000).astype(np.uint64))
+    words = np.concatenate([words, extra.reshape(-1, 1), cluster.reshape(-1, 1)])
+    keys = np.concatenate([keys, np.arange(len(extra) + len(cluster), dtype=np.uint64) + np.uint64(n + 1)])
     t = hip_engine.open_table(0, 1, 8)
     try:
         t.add(keys, words)
@@ -225,14 +234,14 @@ def test_matrix_core_batches_speculate_too(hip_engine, nq):
             return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"], after["mfma_pack_launches"] - before["mfma_pack_launches"]
 
         random_q = rng.integers(1, 2**64, size=3 * nq, dtype=np.uint64)
-        assert ask(random_q[:nq])[:2] == (0, 0)                      # the first search of the segment: nothing to go by
+        assert ask(random_q[:nq])[:2] == (0, 0)                      # the first search of this size class: nothing to go by
         hits, misses, packed = ask(random_q[nq : 2 * nq])
         assert (hits, misses) == (1, 0) and packed >= 1              # random queries after random queries: one packed collect pass
         assert ask(near[:nq])[:2] == (1, 0)                          # all within the radius, far below it
-        mixed = near[nq : 2 * nq].copy()
-        mixed[nq // 2] = random_q[2 * nq]                            # ended at <= 2 + 2: one random query finds nothing there
+        mixed = random_q[:nq].copy()
+        mixed[nq // 2] = centre                                      # 30 000 rows within the radius of one query: its list overflows
         assert ask(mixed)[:2] == (0, 1)
-        assert ask(random_q[2 * nq : 3 * nq])[:2] == (1, 0)          # the miss re-seeded the radius
+        assert ask(random_q[2 * nq : 3 * nq])[:2] == (1, 0)          # the ordinary rerun re-seeded the radius; one miss does not back off
         hip_engine.set_option("spec_max_queries", nq - 1)
         try:
             assert ask(random_q[:nq])[:2] == (0, 0)
