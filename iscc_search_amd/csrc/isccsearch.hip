@@ -27,6 +27,9 @@
 #include <string>
 #include <unordered_map>
 #include <thread>
+#include <atomic>
+#include <functional>
+#include <chrono>
 #include <vector>
 
 #include "../../include/isccsearch.h"
@@ -902,22 +905,90 @@ void unpack_range(const isk::Record* rec, const uint32_t* cnt, uint32_t q_begin,
 
 // Records -> the caller's arrays.  A large block (k in the hundreds x a full batch: 10^5..10^6 records, 0.1-0.5 ms on one core,
 // up to 14 % of such a step) is split by query over a few threads; the usual block (1 024 x 10 records) is done in place.
+// Workers for the host side of LARGE result blocks (a simprint-sized search returns 512 x 400 records: 4.9 MB of {key, distance}
+// records to split into the caller's arrays).  One thread takes 270 us for them, four threads started per call 140 (a thread
+// start costs ~25 us), eight started per call 190-240; the same eight kept waiting here ~60.  Started on first use, one pool per
+// process; a call hands out slices of queries and waits for them.
+class UnpackPool {
+public:
+    static UnpackPool& get() { static UnpackPool pool; return pool; }
+    // runs fn(slice) for slice = 0 .. slices - 1, the caller taking part
+    void run(uint32_t slices, const std::function<void(uint32_t)>& fn) {
+        std::lock_guard<std::mutex> one_at_a_time(call_mu_);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_.wait(lk, [&] { return active_ == 0; });       // (a worker that woke late for the previous call is still leaving)
+            fn_ = &fn;
+            slices_ = slices;
+            next_.store(0, std::memory_order_relaxed);
+            left_ = slices;
+            generation_ += 1;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return left_ == 0; });
+    }
+    uint32_t workers() const { return (uint32_t)threads_.size(); }
+
+private:
+    UnpackPool() {
+        const uint32_t hw = std::thread::hardware_concurrency();
+        const uint32_t n = std::min<uint32_t>(7u, hw > 1 ? hw - 1 : 0);
+        for (uint32_t i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
+    }
+    ~UnpackPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    void work() {
+        for (;;) {
+            const uint32_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= slices_) return;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                active_ += 1;
+            }
+            work();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--active_ == 0) done_.notify_all();
+        }
+    }
+    std::mutex call_mu_, mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(uint32_t)>* fn_ = nullptr;
+    std::atomic<uint32_t> next_{0};
+    uint32_t slices_ = 0, left_ = 0, active_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
 void unpack_records(const isk::Record* rec, const uint32_t* cnt, uint32_t nq, uint32_t k, int key_words,
                     const uint32_t* dest_index /*nullable: original query index per row*/,
                     uint64_t* out_keys, uint32_t* out_h, uint16_t* out_p, uint32_t* out_c) {
     const uint64_t records = (uint64_t)nq * k;
-    const uint32_t hw = std::thread::hardware_concurrency();
-    const uint32_t threads = records < (1u << 17) ? 1u : std::min<uint32_t>({8u, hw ? hw : 1u, nq});
-    if (threads <= 1) {
+    if (records < (1u << 16) || nq < 2) {
         unpack_range(rec, cnt, 0, nq, k, key_words, dest_index, out_keys, out_h, out_p, out_c);
         return;
     }
-    std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < threads; ++t)
-        pool.emplace_back(unpack_range, rec, cnt, (uint32_t)((uint64_t)nq * t / threads), (uint32_t)((uint64_t)nq * (t + 1) / threads), k, key_words,
-                          dest_index, out_keys, out_h, out_p, out_c);
-    unpack_range(rec, cnt, 0, (uint32_t)((uint64_t)nq / threads), k, key_words, dest_index, out_keys, out_h, out_p, out_c);
-    for (auto& th : pool) th.join();
+    UnpackPool& pool = UnpackPool::get();
+    const uint32_t slices = std::min<uint32_t>(nq, 2 * (pool.workers() + 1));
+    pool.run(slices, [&](uint32_t i) {
+        unpack_range(rec, cnt, (uint32_t)((uint64_t)nq * i / slices), (uint32_t)((uint64_t)nq * (i + 1) / slices), k, key_words, dest_index, out_keys, out_h, out_p, out_c);
+    });
 }
 
 void unpack_range(const isk::Record* rec, const uint32_t* cnt, uint32_t q_begin, uint32_t q_end, uint32_t k, int key_words,
