@@ -314,7 +314,9 @@ def main():
     elapsed = max_over_ranks(elapsed)
 
     batched = args.queries > args.tq
-    mfma_on = opts["mfma"] and args.queries >= opts["mfma_min_queries"]
+    # (64-bit codes take the packed matrix-core kernel from 9 queries: engine option mfma_pack_min_queries)
+    mfma_from = min(opts["mfma_min_queries"], opts.get("mfma_pack_min_queries", 9)) if words == 1 and opts.get("mfma_pack", 1) else opts["mfma_min_queries"]
+    mfma_on = bool(opts["mfma"]) and args.queries >= mfma_from and st["scan_mfma_launches"] > 0
 
     def regime_name(mfma, stretch_mb):
         if mfma:
