@@ -332,6 +332,23 @@ def main():
 
     # Outside the timed region (one GPU): the same step in the other regimes.
     extra = {}
+    # The engine starts a step under the k-th distance the previous batch of its size ended at (+ 2 bits) instead of a bootstrap
+    # sample's threshold, and verifies that this held k rows for every query ("hints"): every row is still
+    # scanned, nothing is cached, and the hint is ONE number per batch -- but it is state carried from step to step, so the
+    # same steps without it are timed beside the headline.
+    if world == 1 and (st["spec_hits"] or st["spec_misses"]) and "speculate" not in opts:
+        engine.set_option("speculate", 0)
+        step()
+        el0, s0_ = measure(min(args.steps, 10))
+        engine.set_option("speculate", 1)
+        step()
+        extra["threshold_hint"] = {
+            "steps_started_under_a_hint": int(st["spec_hits"]), "hints_that_did_not_hold": int(st["spec_misses"]),
+            "what": "steps of the timed region whose thresholds started at the previous step's worst k-th distance + 2 (verified; exact either way)",
+            "value_without_hints": args.queries * min(args.steps, 10) / el0,
+            "ms_per_step_without_hints": el0 / min(args.steps, 10) * 1e3,
+            "without_hints": "engine option speculate = 0: bootstrap sample + single pass (batches <= 128 queries: bootstrap + levels), same process, after the timed region",
+        }
     if world == 1 and not args.no_profile and not args.no_extra_legs and batched:
         legs = []
         if mfma_on:

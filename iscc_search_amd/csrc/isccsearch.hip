@@ -190,6 +190,7 @@ struct isccsearch_handle {
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
     bool spec_suppress = false;       // (isccsearch_search_many: the ordinary rerun of a request whose speculative pass just missed)
+    int self_hint = 1;                // batches above spec_max_queries: start the single self-tightening pass under the hint (no bootstrap sample)
     int speculate = 1;                // small batches: try one range-limited pass under the previous search's k-th distance first
     uint32_t spec_max_queries = 128;   // ... batches of up to this many queries
     int mfma_pack = 1;                // 64-bit codes on the matrix cores: two row tiles per accumulator, packed f16 fold (mfma_pack_kernel)
@@ -455,6 +456,8 @@ struct Batch {
     bool multi = false;
     bool mark_overflow = false;         // search_device_async: overflowed queries report COUNT_OVERFLOW instead of being fixed here
     bool allow_self = true, used_self = false;   // the single self-tightening pass, and whether a job of this batch took it
+    int self_hint = -1;       // >= 0: the single pass starts under THIS threshold instead of a bootstrap sample's (search_locked verifies)
+    bool used_hint = false;
     std::vector<Job> jobs;
 
     Batch(H* h_, Table& t_, uint32_t nq_, uint32_t qbytes_, uint32_t k_, isk::Record* out, uint32_t* out_cnt)
@@ -678,8 +681,15 @@ struct Batch {
             bp.thr = self ? h->d_thr.p : nullptr;
             bp.thr_packed = j.pack ? 1u : 0u;          // mfma_pack_kernel keeps (and lowers) its live thresholds packed
             bp.counts = h->d_ghist.p;          // zeroed by the kernel: the running histogram of the levels / the counters of MODE_SELF
+            bp.hint = isk::BOOT_NO_HINT;
             hist_live = true;
-            if (nq_pad > 64 && h->boot_multi) {
+            if (self && self_hint >= 0) {
+                // the threshold a previous batch of this size ended at (+ margin) instead of a sample: no 65 536-row bootstrap, and
+                // the pass starts ~6 bits tighter -- without the flood of its first steps.  Verified by the caller.
+                bp.hint = (uint32_t)self_hint;
+                used_hint = true;
+                hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(64), 0, h->stream, bp);
+            } else if (nq_pad > 64 && h->boot_multi) {
                 // large batches: four queries per 1 024-thread block share every row load of the sample
                 const dim3 bgrid(nq_pad / isk::BOOT_QB), bblock(1024);
                 switch (j.W) {
@@ -1118,6 +1128,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "fold_tau")) { if (value < 0 || value > 32) return fail(-EINVAL, "fold_tau must be 0..32"); h->fold_tau = (uint32_t)value; return 0; }
     if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
+    if (!strcmp(name, "self_hint")) { h->self_hint = value != 0; return 0; }
     if (!strcmp(name, "mfma_pack_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_pack_min_queries must be 1..1024"); h->mfma_pack_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_tighten")) { h->self_tighten = value != 0; return 0; }
@@ -1646,9 +1657,15 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         Segment* spec_seg = nullptr;
         if (segments == 1)
             for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) if (t.seg[b].n) spec_seg = &t.seg[b];
-        const bool small_batch = spec_seg && radius < 0 && !out_freq && one_copy && m <= h->spec_max_queries && k <= spec_seg->n;
-        const bool speculate = small_batch && h->speculate && !h->spec_suppress && spec_seg->hint(m).ready(k);
+        const bool hintable = spec_seg && radius < 0 && !out_freq && one_copy && k <= spec_seg->n;
+        const bool small_batch = hintable && m <= h->spec_max_queries;
+        const bool hint_ready = hintable && h->speculate && !h->spec_suppress && (small_batch || h->self_hint) && spec_seg->hint(m).ready(k);
+        const bool speculate = hint_ready && small_batch;
         if (speculate) batch.radius = (int)spec_seg->hint(m).tau;
+        // LARGER batches keep their single self-tightening pass (one radius for hundreds of queries admits several times the
+        // candidates of per-query thresholds) but START it under the hint instead of a bootstrap sample's threshold: no sample
+        // kernel, no flood of candidates in the first steps.  Verified the same way (`used_hint`).
+        if (hint_ready && !small_batch) batch.self_hint = (int)spec_seg->hint(m).tau;
         bool spec_ok = false;
         auto copy_results = [&]() -> int {
             if (out_freq) {
@@ -1716,22 +1733,45 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             }
         } else {
             // one segment: flags and results travel together, ONE copy and ONE synchronisation per batch
-            if (!one_copy && (rc = batch.copy_flags())) return rc;
-            if ((rc = copy_results())) return rc;
-            HIPOK(hipStreamSynchronize(h->stream));
-            if (!batch.jobs.empty() && batch.used_self && batch.any_flag()) {
-                if ((rc = batch.retry_with_levels(hq.data()))) return rc;
+            auto finish = [&]() -> int {
+                int rf;
+                if (!one_copy && (rf = batch.copy_flags())) return rf;
+                if ((rf = copy_results())) return rf;
+                HIPOK(hipStreamSynchronize(h->stream));
+                if (!batch.jobs.empty() && batch.used_self && batch.any_flag()) {
+                    if ((rf = batch.retry_with_levels(hq.data()))) return rf;
+                    if (!one_copy && (rf = batch.copy_flags())) return rf;
+                    if ((rf = copy_results())) return rf;
+                    HIPOK(hipStreamSynchronize(h->stream));
+                }
+                if (!batch.jobs.empty() && batch.any_flag()) {
+                    if ((rf = batch.fix())) return rf;
+                    if ((rf = copy_results())) return rf;
+                    HIPOK(hipStreamSynchronize(h->stream));
+                }
+                return 0;
+            };
+            if (batch.used_hint) {
+                // the hinted pass holds if no list overflowed and every query found k rows under the hint
                 if (!one_copy && (rc = batch.copy_flags())) return rc;
                 if ((rc = copy_results())) return rc;
                 HIPOK(hipStreamSynchronize(h->stream));
-            }
-            if (!batch.jobs.empty() && batch.any_flag()) {
-                if ((rc = batch.fix())) return rc;
-                if ((rc = copy_results())) return rc;
-                HIPOK(hipStreamSynchronize(h->stream));
-            }
+                bool ok = !batch.any_flag();
+                const uint32_t need = (uint32_t)std::min<uint64_t>(k, spec_seg->n);
+                for (uint32_t i = 0; i < m && ok; ++i) ok = p_cnt[i] >= need;
+                spec_ok = ok;
+                if (ok) h->stats.spec_hits += 1;
+                else {
+                    h->stats.spec_misses += 1;
+                    spec_seg->hint(m).miss();
+                    batch.self_hint = -1;
+                    batch.used_hint = false;
+                    if ((rc = batch.begin(hq.data()))) return rc;
+                    if ((rc = finish())) return rc;
+                }
+            } else if ((rc = finish())) return rc;
         }
-        if (small_batch && !batch.jobs.empty()) {
+        if (hintable && !batch.jobs.empty()) {
             // where this batch's lists ended: the next small batch of this segment starts there (+ 2: P(h <= t) grows ~3x per
             // step at these distances, so the margin costs a handful of candidates and absorbs the spread between queries)
             uint32_t worst = 0;

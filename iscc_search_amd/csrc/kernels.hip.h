@@ -520,7 +520,9 @@ struct BootParams {
     float* thr;               // [nq_pad] out, nullable: tau0 - popc(query) as the MFMA scan compares it (MODE_SELF)
     uint32_t thr_packed;      // ... written PACKED (pack_threshold, scan_params.hip.h) for mfma_pack_kernel
     uint32_t* counts;         // [nq_pad][HB], nullable: zeroed here -- the distance counters of the self-tightening pass
+    uint32_t hint;            // BOOT_NO_HINT, or the threshold itself (no sample): the k-th distance a previous batch of this size ended at + margin
 };
+constexpr uint32_t BOOT_NO_HINT = 0xFFFFFFFFu;
 // the bootstrap threshold (dot-product form: tau0 - popc(query); never = no row can be a candidate) in the scan's representation
 __device__ __forceinline__ void store_boot_threshold(const BootParams& p, uint32_t q, int thr, bool never) {
     if (p.thr_packed) reinterpret_cast<uint32_t*>(p.thr)[q] = never ? 0u : pack_threshold(thr);
@@ -575,10 +577,21 @@ __global__ __launch_bounds__(1024) void boot_kernel(const BootParams p) {
         }
         return;
     }
-    for (uint32_t i = tid; i < 320; i += nthr) hist[i] = 0;
-    __syncthreads();
     uint64_t qw[4];
     for (uint32_t w = 0; w < 4; ++w) qw[w] = w < p.W ? p.queries[(uint64_t)q * 4 + w] : 0;
+    if (p.hint != BOOT_NO_HINT) {      // (uniform: a launch parameter) the threshold is given -- the host verifies that it held k rows
+        if (tid == 0) {
+            p.bias[q] = 0x7FFFFFFFu - p.hint;
+            if (p.thr) {
+                uint32_t pc = 0;
+                for (uint32_t w = 0; w < p.W; ++w) pc += (uint32_t)__builtin_popcountll(w == p.W - 1 ? qw[w] & p.mask_last : qw[w]);
+                store_boot_threshold(p, q, (int)p.hint - (int)pc, false);
+            }
+        }
+        return;
+    }
+    for (uint32_t i = tid; i < 320; i += nthr) hist[i] = 0;
+    __syncthreads();
     // (a large k keeps the whole sample exact: the cut of the first rows must leave >= k rows under it)
     const uint64_t s1 = (p.s0 <= BOOT_EXACT_ROWS || (uint64_t)p.k * 4 > BOOT_EXACT_ROWS) ? p.s0 : BOOT_EXACT_ROWS;
     for (uint64_t r = tid; r < s1; r += nthr) {

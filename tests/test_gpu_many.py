@@ -242,10 +242,97 @@ def test_matrix_core_batches_speculate_too(hip_engine, nq):
         mixed[nq // 2] = centre                                      # 30 000 rows within the radius of one query: its list overflows
         assert ask(mixed)[:2] == (0, 1)
         assert ask(random_q[2 * nq : 3 * nq])[:2] == (1, 0)          # the ordinary rerun re-seeded the radius; one miss does not back off
-        hip_engine.set_option("spec_max_queries", nq - 1)
+        hip_engine.set_option("spec_max_queries", nq - 1)            # one above the limit: the single pass, started under the hint
         try:
-            assert ask(random_q[:nq])[:2] == (0, 0)
+            assert ask(random_q[:nq])[:2] == (1, 0)
+            hip_engine.set_option("self_hint", 0)
+            assert ask(random_q[:nq])[:2] == (0, 0)                  # ... or under its bootstrap sample
         finally:
             hip_engine.set_option("spec_max_queries", 128)
+            hip_engine.set_option("self_hint", 1)
+    finally:
+        t.drop()
+
+
+@pytest.mark.parametrize("nq,k", [(200, 10), (1024, 10), (300, 100)])
+def test_large_batches_start_their_single_pass_under_the_hint(hip_engine, nq, k):
+    """
+    Batches above ``spec_max_queries`` keep the single self-tightening pass but start it under the k-th distance the previous
+    batch of their size ended at (+ 2) instead of a bootstrap sample (option ``self_hint``).  Verified like the speculative pass:
+    a hint that is too tight for some query (random queries after near-duplicates) or a list that overflows (a query inside a
+    30 000-row cluster) sends the batch through the ordinary pass.  Every answer equals the oracle's.
+    """
+    from oracle import oracle_topk
+
+    rng = np.random.default_rng(5000 + nq + k)
+    n = 300_000
+    words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+    near = words[rng.integers(0, n, size=nq), 0] ^ (np.uint64(1) << rng.integers(0, 64, size=nq).astype(np.uint64))
+    extra = np.repeat(near, k + 2) ^ (np.uint64(1) << rng.integers(0, 64, size=nq * (k + 2)).astype(np.uint64))      # k-th distance of `near` <= 2
+    centre = np.uint64(0x5A5A5A5A12345678)
+    cluster = centre ^ (np.uint64(1) << rng.integers(0, 64, size=30_000).astype(np.uint64))
+    words = np.concatenate([words, extra.reshape(-1, 1), cluster.reshape(-1, 1)])
+    keys = rng.permutation(len(words)).astype(np.uint64) + np.uint64(1)
+    t = hip_engine.open_table(0, 1, 8)
+    try:
+        t.add(keys, words)
+
+        def ask(q):
+            q = np.ascontiguousarray(np.asarray(q, dtype=np.uint64).reshape(-1, 1))
+            before = hip_engine.stats()
+            got = t.search(q, None, k)
+            after = hip_engine.stats()
+            exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+            for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                np.testing.assert_array_equal(g, e, err_msg=name)
+            return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"]
+
+        r = rng.integers(1, 2**64, size=8 * nq, dtype=np.uint64)
+        far = np.array([bin(int(x) ^ int(centre)).count("1") >= 28 for x in r])      # (a random query NEAR the cluster would overflow by itself)
+        r = r[far][: 4 * nq]
+        assert len(r) == 4 * nq
+        assert ask(r[:nq]) == (0, 0)                                 # bootstrap sample; seeds the hint
+        assert ask(r[nq : 2 * nq]) == (1, 0)                         # started under the hint
+        with_centre = r[2 * nq : 3 * nq].copy()
+        with_centre[7] = centre
+        assert ask(with_centre) == (0, 1)                            # a list overflows under the hint -> ordinary pass (whose own retry repairs it)
+        assert ask(r[:nq]) == (1, 0)                                 # (one miss does not back off)
+        assert ask(near) == (1, 0)                                   # near-duplicates: far inside the hint, which decays by one bit
+        hip_engine.set_option("self_hint", 0)
+        assert ask(near) == (0, 0)
+        hip_engine.set_option("self_hint", 1)
+    finally:
+        hip_engine.set_option("self_hint", 1)
+        t.drop()
+
+
+def test_a_hint_that_is_too_tight_is_noticed(hip_engine):
+    """Near-duplicate queries seed a hint of a few bits; the random queries that follow find fewer than k rows under it: miss, rerun, exact."""
+    from oracle import oracle_topk
+
+    rng = np.random.default_rng(909)
+    n, nq, k = 200_000, 200, 10
+    words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+    near = words[rng.integers(0, n, size=nq), 0]
+    extra = np.repeat(near, k + 2) ^ (np.uint64(1) << rng.integers(0, 64, size=nq * (k + 2)).astype(np.uint64))
+    words = np.concatenate([words, extra.reshape(-1, 1)])
+    keys = rng.permutation(len(words)).astype(np.uint64) + np.uint64(1)
+    t = hip_engine.open_table(0, 1, 8)
+    try:
+        t.add(keys, words)
+
+        def ask(q):
+            q = np.ascontiguousarray(np.asarray(q, dtype=np.uint64).reshape(-1, 1))
+            before = hip_engine.stats()
+            got = t.search(q, None, k)
+            after = hip_engine.stats()
+            exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+            for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                np.testing.assert_array_equal(g, e, err_msg=name)
+            return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"]
+
+        assert ask(near) == (0, 0)                                   # seeds the hint at <= 1 + 2 bits
+        assert ask(rng.integers(1, 2**64, size=nq, dtype=np.uint64)) == (0, 1)
+        assert ask(rng.integers(1, 2**64, size=nq, dtype=np.uint64)) == (1, 0)
     finally:
         t.drop()
