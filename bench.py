@@ -369,6 +369,11 @@ def main():
         engine.set_option("mfma", opts["mfma"])
         engine.set_option("stretch_mb", opts["stretch_mb"])
 
+    if sharded.hint_hits or sharded.hint_misses:
+        # (sharded steps: every shard starts under the GLOBAL k-th distance of the previous step + 2; the merged lists are checked)
+        extra["threshold_hint"] = {"steps_started_under_a_hint": sharded.hint_hits, "hints_that_did_not_hold": sharded.hint_misses,
+                                   "what": "all steps of this process (gate, settle, warm-up, timed): shards started under the previous step's global k-th "
+                                           "distance + 2; a step stands only if every merged list holds k rows (sharded.py)"}
     total_queries = args.queries * args.steps
     qps = total_queries / elapsed
     out = {

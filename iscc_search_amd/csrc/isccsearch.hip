@@ -190,6 +190,7 @@ struct isccsearch_handle {
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
     bool spec_suppress = false;       // (isccsearch_search_many: the ordinary rerun of a request whose speculative pass just missed)
+    int device_search_hint = -1;      // one-shot: the next isccsearch_search_device_async starts its single pass under this threshold (the caller verifies)
     int self_hint = 1;                // batches above spec_max_queries: start the single self-tightening pass under the hint (no bootstrap sample)
     int speculate = 1;                // small batches: try one range-limited pass under the previous search's k-th distance first
     uint32_t spec_max_queries = 128;   // ... batches of up to this many queries
@@ -1128,6 +1129,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "fold_tau")) { if (value < 0 || value > 32) return fail(-EINVAL, "fold_tau must be 0..32"); h->fold_tau = (uint32_t)value; return 0; }
     if (!strcmp(name, "level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "level_growth must be 2..1024"); h->level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
+    if (!strcmp(name, "device_search_hint")) { if (value < -1 || value > 8 * ISCCSEARCH_MAX_BYTES) return fail(-EINVAL, "device_search_hint must be -1..256"); h->device_search_hint = (int)value; return 0; }
     if (!strcmp(name, "self_hint")) { h->self_hint = value != 0; return 0; }
     if (!strcmp(name, "mfma_pack_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_pack_min_queries must be 1..1024"); h->mfma_pack_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
@@ -2218,6 +2220,10 @@ int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_
             Batch batch(h, t, nq, len, k, static_cast<isk::Record*>(d_records), d_counts);
             batch.radius = radius;
             batch.mark_overflow = true;
+            // (sharded callers: the GLOBAL k-th distance of the previous step + margin -- every shard then lists its rows under it,
+            //  tightening as it finds k of its own, and the caller accepts the merged lists only if they hold k rows per query)
+            if (radius < 0 && h->device_search_hint >= 0) batch.self_hint = h->device_search_hint;
+            h->device_search_hint = -1;
             if ((rc = batch.begin(q_words))) return rc;
             HIPOK(hipEventRecord(h->ev_done, h->stream));
             HIPOK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->ev_done, 0));
@@ -2226,6 +2232,7 @@ int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_
     }
     // several segments (their lists must be fixed and merged with the host's help), oversized batches, bad arguments: the
     // synchronous path does the work and the reporting; the results are complete when it returns
+    h->device_search_hint = -1;
     return search_device_impl(h, table, nq, q_words, q_nbytes, k, radius, d_records, d_counts);
 }
 

@@ -367,12 +367,15 @@ class HipTable:
                 self.engine.handle, self.id, n, _lib.ptr(keys, ctypes.c_uint64), int(dup_limit), _lib.ptr(out, ctypes.c_uint32)))
         return out
 
-    def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr, max_hamming=None, consumer_stream=None):
-        # type: (np.ndarray, np.ndarray | None, int, int, int, int | None, int | None) -> None
+    def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr, max_hamming=None, consumer_stream=None, hint=None):
+        # type: (np.ndarray, np.ndarray | None, int, int, int, int | None, int | None, int | None) -> None
         """
         Same search (range-limited when ``max_hamming`` is given), results left in caller-owned device memory.  With
         ``consumer_stream`` (a HIP stream handle) the call does not wait for the GPU: that stream is made to wait for the
         results instead, and overflowed queries come back with a count of ``_lib.COUNT_OVERFLOW`` (``isccsearch_search_device_async``).
+        ``hint`` (asynchronous top-k searches only): the single pass starts under this Hamming distance instead of a bootstrap
+        sample's threshold, so the lists hold this table's nearest rows WITHIN the hint -- fewer than k if it was too tight;
+        the caller must check that (``ShardedTable`` does, on the merged lists).
         """
         q_words = self._words(q_words)
         nq = q_words.shape[0]
@@ -380,6 +383,8 @@ class HipTable:
         lib, args = self.engine._lib, (self.engine.handle, self.id, nq, _lib.ptr(q_words, ctypes.c_uint64), _lib.ptr(q_nbytes, ctypes.c_uint8), k)
         out = (ctypes.c_void_p(d_records_ptr), ctypes.c_void_p(d_counts_ptr))
         if consumer_stream is not None:
+            if hint is not None and max_hamming is None:
+                self.engine.set_option("device_search_hint", int(hint))      # one-shot, consumed by the call below
             _lib.check(lib.isccsearch_search_device_async(*args, -1 if max_hamming is None else int(max_hamming), *out, ctypes.c_void_p(consumer_stream)))
             return
         if max_hamming is None:

@@ -13,6 +13,8 @@ second collective: at 160 KB per rank for 1 024 queries the exchange is latency 
 C-ABI); tests drive the same class over gloo with an oracle-backed ops object.
 """
 
+import os
+
 import numpy as np
 
 RECORD_BYTES = 24
@@ -57,9 +59,12 @@ class HipShardOps:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def local_search(self, q_words, q_nbytes, k, max_hamming=None, synchronous=False):
+    supports_hint = True
+
+    def local_search(self, q_words, q_nbytes, k, max_hamming=None, synchronous=False, hint=None):
         """
-        One device block {records | counts} holding this shard's exact top-k (within ``max_hamming`` if given).
+        One device block {records | counts} holding this shard's exact top-k (within ``max_hamming`` if given; with ``hint``: its
+        nearest rows within that distance -- fewer than k when the hint was too tight, which ``ShardedTable`` notices after the merge).
 
         Asynchronous by default: the search is queued on the library's stream and torch's current stream -- the one the
         all-gather is issued on -- waits for it on the device; nothing waits on the host.  ``synchronous`` runs the
@@ -69,7 +74,7 @@ class HipShardOps:
         rec_bytes, blk = block_bytes(nq, k)
         buf = self.buffer("block", blk)
         self.table.search_device(q_words, q_nbytes, k, buf.data_ptr(), buf.data_ptr() + rec_bytes, max_hamming=max_hamming,
-                                 consumer_stream=None if synchronous else self._stream())
+                                 consumer_stream=None if synchronous else self._stream(), hint=None if synchronous else hint)
         return buf
 
     def buffer(self, name, nbytes):
@@ -121,6 +126,13 @@ class ShardedTable:
         self.assets_share_a_rank = assets_share_a_rank
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # (batch-size class, k) -> [hint, batches still to skip, penalty]: the GLOBAL k-th distance the previous step of that shape
+        # ended at + 2.  Every shard starts its pass under it (no bootstrap sample; the lists hold the shard's rows within the hint),
+        # and the step stands if every merged list holds k rows -- they all lie within the hint, so nothing nearer was left out.
+        # The merged lists are the same on every rank, hence so is every decision taken from them.
+        self.use_hints = bool(getattr(ops, "supports_hint", False)) and not os.environ.get("ISCC_NO_SHARD_HINT")
+        self._hints = {}
+        self.hint_hits = self.hint_misses = 0
 
     def search(self, q_words, q_nbytes, k):
         # type: (np.ndarray, np.ndarray | None, int) -> tuple
@@ -184,11 +196,33 @@ class ShardedTable:
         return t.cpu().numpy()
 
     def _search(self, q_words, q_nbytes, k, max_hamming):
+        nq = q_words.shape[0]
+        alone = self.world_size == 1 and not (self.always_gather and self.dist.is_initialized())
+        state = None
+        if self.use_hints and max_hamming is None and nq and not alone:
+            state = self._hints.setdefault((int(nq).bit_length(), int(k)), [None, 0, 0])
+            if state[0] is not None and state[1] == 0:
+                out = self._exchange(q_words, q_nbytes, k, None, {"hint": state[0]})
+                cnt = out[3]
+                if not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k:
+                    worst = int(out[1][:, k - 1].max())
+                    state[0], state[2] = max(worst + 2, state[0] - 1), 0          # decays by one bit per step towards what the batches need
+                    self.hint_hits += 1
+                    return out
+                self.hint_misses += 1
+                state[2] = min(2 * state[2] + 1, 15)                             # a miss: 0, 2, 6, 14 steps without a hint for 1, 2, 3, 4 in a row
+                state[1] = state[2] - 1
+            elif state[1]:
+                state[1] -= 1
         out = self._exchange(q_words, q_nbytes, k, max_hamming, {})
         if np.any(out[3] == COUNT_OVERFLOW):
             # some shard's candidate list overflowed and the asynchronous search could only mark it; the merged counts are
             # the same on every rank, so every rank repeats the step through the synchronous path (exact fallback) together
             out = self._exchange(q_words, q_nbytes, k, max_hamming, {"synchronous": True})
+        if state is not None:
+            cnt = out[3]
+            full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
+            state[0] = int(out[1][:, k - 1].max()) + 2 if full else None       # (a table with fewer than k rows never gets a hint)
         return out
 
     def _exchange(self, q_words, q_nbytes, k, max_hamming, how):

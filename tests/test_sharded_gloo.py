@@ -27,7 +27,12 @@ class OracleShardOps:
         self.table = table
         self.key_words = table.key_words
 
-    def local_search(self, q_words, q_nbytes, k, max_hamming=None, synchronous=False):
+    supports_hint = False      # HintedOracleShardOps below: the single pass started under a hint lists the rows WITHIN it
+
+    def local_search(self, q_words, q_nbytes, k, max_hamming=None, synchronous=False, hint=None):
+        if hint is not None and max_hamming is None:
+            type(self).hinted_calls = getattr(type(self), "hinted_calls", 0) + 1
+            max_hamming = hint
         rec, cnt = self.table.search_records(q_words, q_nbytes, k, max_hamming)
         nq = q_words.shape[0]
         rec_bytes, blk = block_bytes(nq, k)
@@ -221,3 +226,60 @@ def test_one_shard_takes_the_direct_entry_point_when_the_ops_offer_one():
         np.testing.assert_array_equal(a, b)
     for a, b in zip(got_within, plain.search_within(q, qlens, 12, 1)):
         np.testing.assert_array_equal(a, b)
+
+
+class HintedOracleShardOps(OracleShardOps):
+    supports_hint = True
+
+
+def _hint_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(4711)
+        n, nq, k = 6000, 5, 8
+        words = rng.integers(0, 2**64, size=(n, 1), dtype=np.uint64)
+        dup = np.uint64(0x0F0F0F0F0F0F0F0F)
+        words[:40, 0] = dup ^ (np.uint64(1) << rng.integers(0, 64, size=40).astype(np.uint64))     # 40 rows one bit off `dup`
+        keys = rng.permutation(n).astype(np.uint64) + np.uint64(3)
+        lo, hi = shard_range(n, rank, world)
+        table = OracleTable(0, 1, 8)
+        table.add(keys[lo:hi], words[lo:hi])
+        HintedOracleShardOps.hinted_calls = 0
+        sharded = ShardedTable(HintedOracleShardOps(table))
+        assert sharded.use_hints
+        random_q = rng.integers(0, 2**64, size=(4 * nq, 1), dtype=np.uint64)
+        near_q = np.full((nq, 1), dup, dtype=np.uint64)
+        log = []
+
+        def ask(q):
+            before = HintedOracleShardOps.hinted_calls
+            got = sharded.search(q, None, k)
+            exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=8)
+            for g, e in zip(got, exp):
+                np.testing.assert_array_equal(g, e)
+            log.append(HintedOracleShardOps.hinted_calls - before)
+
+        ask(random_q[:nq])            # 0: nothing to go by; seeds the GLOBAL k-th distance + 2
+        ask(random_q[nq : 2 * nq])    # 1: every shard starts under it; the merged lists hold k rows: stands
+        ask(near_q)                   # 1: far inside the hint (which decays by one bit)
+        ask(random_q[2 * nq : 3 * nq])   # 1
+        sharded._hints[(int(nq).bit_length(), k)][0] = 3    # a hint that is too tight for random queries ...
+        ask(random_q[3 * nq :])       # 1: ... the merged lists come up short: the step is repeated without it (and re-seeds)
+        ask(random_q[:nq])            # 1: one miss does not back off
+        assert log == [0, 1, 1, 1, 1, 1], log
+        ask(near_q[:2])               # another batch-size class: its own hint
+        assert log[-1] == 0
+        np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array(log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shards_start_under_the_global_kth_distance_of_the_previous_step(tmp_path):
+    """Hit, decay, miss and re-seed of the sharded hint, two ranks over gloo, every answer against the unsharded oracle."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_hint_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0.npy", "ok1.npy"]
