@@ -117,7 +117,10 @@ const char* isccsearch_last_error(void);
  * instead of threshold levels growing by "mfma_level_growth" (4)); "mfma_pack" (0|1, default 1: 64-bit codes run the packed
  * form of that kernel -- two row tiles per accumulator, v_pk_minimum3_f16 fold -- unless the batch holds an all-zero query);
  * "speculate" (0|1, default 1: a batch of up to "spec_max_queries" (128) queries over a one-segment table is first tried as ONE
- * range-limited pass under the k-th distance the previous such search ended at + 2, and verified: exact either way);
+ * range-limited pass under the k-th distance the previous such search ended at + 2, and verified: exact either way; larger
+ * batches START their single pass under that hint instead of a bootstrap sample's threshold, "self_hint" (0|1, default 1), verified
+ * the same way; "device_search_hint" (-1 | 0..256, one-shot): the next isccsearch_search_device_async starts under THIS distance and
+ * its lists hold the table's nearest rows within it -- fewer than k if it was too tight, which the caller must check (sharded.py));
  * "candidate_cap" (16 384: floor of the per-query candidate
  * buffer, in entries); "queries_per_pass" (8|16, XOR + popcount kernel), "profile"
  * (0|1: time every collect-scan launch with HIP events, read back through isccsearch_stats_get), "stretch_mb" (XOR + popcount
