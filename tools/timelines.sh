@@ -8,7 +8,7 @@ O=$ROOT/gpurun_out/${TAG}_tl
 OUT=$ROOT/gpurun_out/${TAG}_step_timelines.txt
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-legs --no-other-configs --no-profile --settle-steps 10 --steps 10 --warmup 2"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-legs --no-other-configs --no-profile --settle-steps 10 --steps 10 --warmup 2 --opt speculate=1"     # (the option named: bench.py then skips its without-hints leg, so the trace ends with ordinary steady-state steps)
 : > "$OUT"
 one() {   # name, bench args...
     local name=$1; shift
