@@ -62,3 +62,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         oc = out["other_configs"][name]
         assert oc["queries_per_s"] > 0 and oc["parity_checked_queries"] == 4 and str(bits) in oc["workload"]
         assert oc["roofline"] is None or 0 < oc["roofline"]["frac"] <= 1.0
+    # the steps of the timed region start under the previous step's k-th distance (a hint carried from step to step, verified):
+    # the line says so and times the same steps without it
+    hint = out["threshold_hint"]
+    assert hint["steps_started_under_a_hint"] + hint["hints_that_did_not_hold"] >= 1
+    assert hint["value_without_hints"] > 0 and hint["ms_per_step_without_hints"] > 0
