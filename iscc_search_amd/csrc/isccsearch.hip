@@ -202,7 +202,9 @@ struct isccsearch_handle {
     bool boot_multi = true;           // large batches: boot_multi_kernel (four queries per block share the sample's row loads)
     uint32_t candidate_cap = 16384;   // floor of the per-query candidate buffer (entries); tests shrink it to reach the overflow paths
     uint32_t self_refresh_steps = 1;  // steps of a full chunk between two looks at the live thresholds (power of two)
-    uint32_t self_max_k = 512;        // the unpruned lists hold ~17 k entries + the first steps' flood: see the cap in Batch::begin
+    uint32_t self_max_k = ISCCSEARCH_MAX_K;   // (512 until the single pass was measured beyond it: k = 1 000 / 2 000 over 100 M rows 6.0 / 9.0 ms against
+                                      //  8.5 / 14.0 of the level design, 4.2 / 6.6 under a hint -- tools/ab_self_max_k.sh; the unpruned lists hold
+                                      //  ~k ln(n / sample) entries + the first steps' flood: see the cap in Batch::begin)
                                       // (100 M rows, k = 100 / 256 / 512: 3.80 / 4.52 / 6.04 ms against 4.60 / 5.35 / 7.37 with levels)
     uint64_t self_boot_rows = 65536;  // its bootstrap sample: all waves start under the sample's threshold at once, so a
                                       // short sample floods the first steps with candidates (4 096 rows: ~860 per query)
@@ -1140,7 +1142,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
         h->self_refresh_steps = (uint32_t)value; return 0;
     }
     if (!strcmp(name, "candidate_cap")) { if (value < 64 || value > (1 << 22)) return fail(-EINVAL, "candidate_cap must be 64..4194304"); h->candidate_cap = (uint32_t)value; return 0; }
-    if (!strcmp(name, "self_max_k")) { if (value < 1 || value > 512) return fail(-EINVAL, "self_max_k must be 1..512"); h->self_max_k = (uint32_t)value; return 0; }
+    if (!strcmp(name, "self_max_k")) { if (value < 1 || value > ISCCSEARCH_MAX_K) return fail(-EINVAL, "self_max_k must be 1..%d", ISCCSEARCH_MAX_K); h->self_max_k = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_pack")) { h->mfma_pack = value != 0; return 0; }

@@ -336,3 +336,30 @@ def test_a_hint_that_is_too_tight_is_noticed(hip_engine):
         assert ask(rng.integers(1, 2**64, size=nq, dtype=np.uint64)) == (1, 0)
     finally:
         t.drop()
+
+
+@pytest.mark.parametrize("nbytes,n,nq,k", [(8, 150_000, 150, 700), (8, 120_000, 40, 4096), (16, 100_000, 150, 2048), (32, 80_000, 64, 1000)])
+def test_the_single_pass_serves_every_k(hip_engine, nbytes, n, nq, k):
+    """``self_max_k`` = 4 096: large k takes the single self-tightening pass too (bootstrap sample, then under the hint); both against the oracle."""
+    from oracle import oracle_topk
+
+    rng = np.random.default_rng(31 + nbytes + k)
+    w = (nbytes + 7) // 8
+    words = rng.integers(0, 2**64, size=(n, w), dtype=np.uint64)
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
+    t = hip_engine.open_table(0, 1, nbytes)
+    try:
+        t.add(keys, words)
+        for rnd in range(3):
+            q = rng.integers(0, 2**64, size=(nq, w), dtype=np.uint64)
+            q[: nq // 4] = words[rng.integers(0, n, size=nq // 4)]
+            before = hip_engine.stats()
+            got = t.search(q, None, k)
+            after = hip_engine.stats()
+            assert after["level_launches"] == before["level_launches"], "large k fell back to the level design"
+            assert (after["spec_hits"] + after["spec_misses"] > before["spec_hits"] + before["spec_misses"]) == (rnd > 0)
+            exp = oracle_topk(0, keys, words, None, q, None, k, fixed_nbytes=nbytes)
+            for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                np.testing.assert_array_equal(g, e, err_msg=f"round {rnd}: {name}")
+    finally:
+        t.drop()

@@ -14,7 +14,7 @@ echo "# batch size (100 M x 64-bit, k = 10): <= 8 queries run the XOR + popcount
 for q in 1 4 8 9 12 16 17 32 64 96 128 192 256 512; do run --queries $q; done
 for q in 1 8 16 32 64 128; do run --queries $q --opt speculate=0; done
 echo "# k"
-for k in 1 100 256 512 1000; do run --k $k; done
+for k in 1 100 256 512 1000 2000; do run --k $k; done
 echo "# code length (Hamming tables of 128 / 192 / 256-bit codes) and config 3 (NPHD table of 256-bit units)"
 run --nbytes 16; run --nbytes 24; run --nbytes 32; run --nbytes 32 --metric nphd
 echo "# shards of the 100 M-row index with the collective enabled on ONE GPU (rehearsal, not a scaling result), and config 4's shard and index"
