@@ -36,7 +36,7 @@ def main():
     mismatches = 0
     for rnd in range(rounds):
         nq = int(rng.choice([17, 40, 64, 70, 96, 128, 160, 200, 512, 1000, 1024]))
-        k = int(rng.choice([1, 10, 10, 10, 37, 100, 256, 512]))
+        k = int(rng.choice([1, 10, 10, 10, 37, 100, 256, 512, 1000, 2048]))
         q = rng.integers(0, 2**64, size=(nq, words), dtype=np.uint64)
         planted = rng.random(nq) < rng.choice([0.0, 0.25, 0.9])
         _, stored = table.export_rows(nbytes, int(rng.integers(0, rows - nq)), nq)
