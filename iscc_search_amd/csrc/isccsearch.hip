@@ -95,8 +95,10 @@ struct Segment {
         void hit(uint32_t worst) { penalty = 0; tau = std::min<uint32_t>(std::max<uint32_t>(worst + 2, tau ? tau - 1 : 0), 8 * ISCCSEARCH_MAX_BYTES); }
         void miss() { penalty = std::min<uint32_t>(2 * penalty + 1, 15); skip = penalty - 1; }      // (the rerun that follows is the first skipped batch)
         void seed(uint32_t new_k, uint32_t worst) { k = new_k; tau = std::min<uint32_t>(worst + 2, 8 * ISCCSEARCH_MAX_BYTES); }
-    } spec[12];
-    SpecHint& hint(uint32_t nq) { return spec[nq ? 32 - __builtin_clz(nq) : 0]; }      // 1 | 2-3 | 4-7 | ... | 1024
+    } spec[12][5];
+    // one hint per batch-size class (1 | 2-3 | 4-7 | ... | 1024) and per compared PREFIX length (8 / 16 / 24 / 32 bytes and the odd ones:
+    // an NPHD table of 256-bit rows answers 64-bit queries over a 64-bit prefix, whose k-th distance has nothing to do with a 256-bit one's)
+    SpecHint& hint(uint32_t nq, uint32_t len) { return spec[nq ? 32 - __builtin_clz(nq) : 0][len % 8 == 0 && len >= 8 && len <= 32 ? len / 8 : 0]; }
 };
 
 struct Table {
@@ -1663,13 +1665,13 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) if (t.seg[b].n) spec_seg = &t.seg[b];
         const bool hintable = spec_seg && radius < 0 && !out_freq && one_copy && k <= spec_seg->n;
         const bool small_batch = hintable && m <= h->spec_max_queries;
-        const bool hint_ready = hintable && h->speculate && !h->spec_suppress && (small_batch || h->self_hint) && spec_seg->hint(m).ready(k);
+        const bool hint_ready = hintable && h->speculate && !h->spec_suppress && (small_batch || h->self_hint) && spec_seg->hint(m, len).ready(k);
         const bool speculate = hint_ready && small_batch;
-        if (speculate) batch.radius = (int)spec_seg->hint(m).tau;
+        if (speculate) batch.radius = (int)spec_seg->hint(m, len).tau;
         // LARGER batches keep their single self-tightening pass (one radius for hundreds of queries admits several times the
         // candidates of per-query thresholds) but START it under the hint instead of a bootstrap sample's threshold: no sample
         // kernel, no flood of candidates in the first steps.  Verified the same way (`used_hint`).
-        if (hint_ready && !small_batch) batch.self_hint = (int)spec_seg->hint(m).tau;
+        if (hint_ready && !small_batch) batch.self_hint = (int)spec_seg->hint(m, len).tau;
         bool spec_ok = false;
         auto copy_results = [&]() -> int {
             if (out_freq) {
@@ -1719,7 +1721,7 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             if (ok) h->stats.spec_hits += 1;
             else {
                 h->stats.spec_misses += 1;
-                spec_seg->hint(m).miss();
+                spec_seg->hint(m, len).miss();
                 batch.radius = -1;
                 if ((rc = batch.begin(hq.data()))) return rc;
                 if ((rc = copy_results())) return rc;
@@ -1767,7 +1769,7 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 if (ok) h->stats.spec_hits += 1;
                 else {
                     h->stats.spec_misses += 1;
-                    spec_seg->hint(m).miss();
+                    spec_seg->hint(m, len).miss();
                     batch.self_hint = -1;
                     batch.used_hint = false;
                     if ((rc = batch.begin(hq.data()))) return rc;
@@ -1781,8 +1783,8 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             uint32_t worst = 0;
             for (uint32_t i = 0; i < m; ++i)
                 if (p_cnt[i]) worst = std::max<uint32_t>(worst, p_rec[(size_t)i * k + p_cnt[i] - 1].hamming);
-            if (spec_ok) spec_seg->hint(m).hit(worst);
-            else spec_seg->hint(m).seed(k, worst);
+            if (spec_ok) spec_seg->hint(m, len).hit(worst);
+            else spec_seg->hint(m, len).seed(k, worst);
         }
         if (out_freq) {
             if (batch.jobs.empty()) for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = 0;
@@ -1935,6 +1937,7 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         size_t block_off = 0, rec_bytes = 0;
         Segment* seg = nullptr;
         bool small = false, spec = false;
+        uint32_t len = 0;      // compared prefix length of the request (the hint is kept per length)
     };
     std::vector<Slot> slots(n);
     std::vector<bool> deferred(n, false);
@@ -1995,8 +1998,9 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
         // small top-k batches: the speculative single pass of search_locked (see there), verified in pass 3a
         for (uint32_t bb = 1; bb <= ISCCSEARCH_MAX_BYTES; ++bb) if (t.seg[bb].n) sl.seg = &t.seg[bb];
         sl.small = r.max_hamming < 0 && r.nq <= h->spec_max_queries && sl.seg && r.k <= sl.seg->n;
-        sl.spec = sl.small && h->speculate && sl.seg->hint(r.nq).ready(r.k);
-        if (sl.spec) b.radius = (int)sl.seg->hint(r.nq).tau;
+        sl.len = len;
+        sl.spec = sl.small && h->speculate && sl.seg->hint(r.nq, len).ready(r.k);
+        if (sl.spec) b.radius = (int)sl.seg->hint(r.nq, len).tau;
         b.pq_off = pq_off;
         b.d_flags = d_cnt + r.nq;
         b.h_flags = p_cnt + r.nq;
@@ -2027,15 +2031,15 @@ int isccsearch_search_many(isccsearch_handle* h, uint32_t n, isccsearch_request*
             const uint32_t need = (uint32_t)std::min<uint64_t>(r.k, sl.seg->n);
             for (uint32_t q = 0; q < r.nq && ok; ++q) ok = p_cnt[q] >= need;
             if (ok) h->stats.spec_hits += 1;
-            else { h->stats.spec_misses += 1; sl.seg->hint(r.nq).miss(); ordinary[i] = true; respec[i] = false; continue; }      // (the ordinary path re-seeds the radius)
+            else { h->stats.spec_misses += 1; sl.seg->hint(r.nq, sl.len).miss(); ordinary[i] = true; respec[i] = false; continue; }      // (the ordinary path re-seeds the radius)
         }
         if (!b.jobs.empty() && b.any_flag()) { ordinary[i] = true; continue; }   // rare: exact fallback through the normal path
         if (sl.small && !b.jobs.empty()) {
             uint32_t worst = 0;
             for (uint32_t q = 0; q < r.nq; ++q)
                 if (p_cnt[q]) worst = std::max<uint32_t>(worst, p_rec[(size_t)q * r.k + p_cnt[q] - 1].hamming);
-            if (sl.spec) sl.seg->hint(r.nq).hit(worst);
-            else sl.seg->hint(r.nq).seed(r.k, worst);
+            if (sl.spec) sl.seg->hint(r.nq, sl.len).hit(worst);
+            else sl.seg->hint(r.nq, sl.len).seed(r.k, worst);
         }
         unpack_records(p_rec, p_cnt, r.nq, r.k, h->tables[r.table]->key_words, nullptr, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count);
     }

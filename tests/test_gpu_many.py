@@ -363,3 +363,40 @@ def test_the_single_pass_serves_every_k(hip_engine, nbytes, n, nq, k):
                 np.testing.assert_array_equal(g, e, err_msg=f"round {rnd}: {name}")
     finally:
         t.drop()
+
+
+def test_hints_are_kept_per_prefix_length(hip_engine):
+    """
+    An NPHD table of 256-bit rows answers 64-bit queries over a 64-bit prefix: their k-th distance (~10 bits) and a 256-bit query's
+    (~95) must not share a hint -- alternating them keeps hitting, and every answer equals the oracle's.
+    """
+    from oracle import oracle_topk
+
+    rng = np.random.default_rng(2468)
+    n, k = 120_000, 10
+    words = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    lens = np.full(n, 32, dtype=np.uint8)
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
+    t = hip_engine.open_table(1, 1, 32)
+    try:
+        t.add(keys, words, lens)
+
+        def ask(nq, nbytes):
+            q = rng.integers(0, 2**64, size=(nq, 4), dtype=np.uint64)
+            q[:, (nbytes + 7) // 8 :] = 0
+            ql = np.full(nq, nbytes, dtype=np.uint8)
+            before = hip_engine.stats()
+            got = t.search(q, ql, k)
+            after = hip_engine.stats()
+            exp = oracle_topk(1, keys, words, lens, q, ql, k)
+            for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                np.testing.assert_array_equal(g, e, err_msg=name)
+            return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"]
+
+        for nq in (3, 200):
+            assert ask(nq, 32) == (0, 0) and ask(nq, 8) == (0, 0)        # each length seeds its own hint
+            for _ in range(3):
+                assert ask(nq, 32) == (1, 0)
+                assert ask(nq, 8) == (1, 0)
+    finally:
+        t.drop()
