@@ -105,6 +105,21 @@ struct Table {
     bool open = false;
     int metric = 0, key_words = 1, max_bytes = 0, max_words = 0;
     Segment seg[ISCCSEARCH_MAX_BYTES + 1];
+    // Tables of SEVERAL code lengths (an ISCC-UNIT index): the hint is the worst k-th NPHD (distance / compared bits) the previous
+    // batch of that size and query length ended at; every segment then lists its rows within (ratio + 1/32) x its compared bits.
+    struct RatioHint {
+        uint32_t k = 0, skip = 0, penalty = 0;
+        double ratio = 0.0;
+        bool ready(uint32_t want_k) {
+            if (k != want_k) return false;
+            if (skip) { skip -= 1; return false; }
+            return true;
+        }
+        void hit(double worst) { penalty = 0; ratio = std::max(worst, ratio - 1.0 / 256.0); }
+        void miss() { penalty = std::min<uint32_t>(2 * penalty + 1, 15); skip = penalty - 1; }
+        void seed(uint32_t new_k, double worst) { k = new_k; ratio = worst; }
+    } mspec[12][5];
+    RatioHint& mhint(uint32_t nq, uint32_t len) { return mspec[nq ? 32 - __builtin_clz(nq) : 0][len % 8 == 0 && len >= 8 && len <= 32 ? len / 8 : 0]; }
     bool indexed = false;
     KeyMap index;
     uint64_t total = 0;
@@ -453,6 +468,8 @@ struct Batch {
     uint32_t* d_out_cnt;      // [nq]     device
     int tq = 8;
     int radius = -1;          // >= 0: report only rows within this Hamming distance (fixed threshold, no sampling)
+    double radius_ratio = -1.0;   // >= 0 (speculative pass over SEVERAL segments): per segment, rows within ratio x compared bits
+    bool ratio_starts_self = false;   // ... as the START of each segment's single self-tightening pass (large batches) instead of a fixed radius
     size_t pq_off = 0;                  // this batch's slice of the pinned query staging buffer (words)
     uint32_t* d_flags = nullptr;        // overflow flags [jobs][nq_pad]; the caller may place them inside its result block
     const uint32_t* h_flags = nullptr;  // where the host finds them after the copy (default: h->p_flags)
@@ -468,6 +485,13 @@ struct Batch {
     Batch(H* h_, Table& t_, uint32_t nq_, uint32_t qbytes_, uint32_t k_, isk::Record* out, uint32_t* out_cnt)
         : h(h_), t(t_), nq(nq_), qbytes(qbytes_), k(k_), d_out(out), d_out_cnt(out_cnt) {}
 
+    int ratio_bits(const Job& j) const { const int bits = 8 * (int)j.pbytes; return std::min(bits, (int)std::floor(radius_ratio * bits)); }
+    // the fixed threshold of a job's range-limited pass, or -1
+    int job_radius(const Job& j) const {
+        if (radius >= 0) return radius;
+        if (radius_ratio >= 0 && !ratio_starts_self) return ratio_bits(j);
+        return -1;
+    }
     struct Ctx { isk::ScanParams sp; isk::SelectParams sl; };
     Ctx make_ctx(size_t ji) const {
         const Job& j = jobs[ji];
@@ -559,7 +583,7 @@ struct Batch {
         }
         cap = std::max<uint32_t>(h->candidate_cap, 16 * k);
         // the self-tightening pass never prunes: ~17 k entries per query over 100 M rows (+ the flood of the first steps)
-        if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0) cap = std::max<uint32_t>(cap, 64 * k);
+        if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0 && radius_ratio < 0) cap = std::max<uint32_t>(cap, 64 * k);
         multi = jobs.size() > 1;
         P = next_pow2(std::max<uint32_t>(k, 1024));   // select's LDS sort buffer: room for small tie classes (12-20 KB)
         sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
@@ -597,6 +621,7 @@ struct Batch {
             Segment& s = *j.seg;
             Ctx c = make_ctx(ji);
             isk::ScanParams& sp = c.sp;
+            const int jr = job_radius(j);
 
             // the collect pass over rows [from, n) within the thresholds in force.  With more than one query group the
             // rows are taken in STRETCHES that fit the Infinity Cache (option "stretch_mb", default 128 of its
@@ -626,7 +651,7 @@ struct Batch {
                     // folded fast path of scan_adapt_kernel switch on as the pass advances)
                     // (the last stretch keeps the histogram too -- a handful of atomics -- so that the whole pass is ONE
                     // kernel instantiation, MODE_STRETCH; it just is not followed by a pick)
-                    const bool hist_too = h->repick && radius < 0;
+                    const bool hist_too = h->repick && jr < 0;
                     const bool repick = hist_too && b < s.n && !self;
                     if (self) {
                         if ((rcl = scan(j, sp, isk::MODE_SELF, false))) return rcl;
@@ -651,16 +676,16 @@ struct Batch {
                 return 0;
             };
 
-            if (radius >= 0) {
+            if (jr >= 0) {
                 // range-limited search: the threshold is given, so one streaming pass collects everything
                 if (inline_queries) {
                     isk::InlineQueries iq;
                     memcpy(iq.w, pq, (size_t)nq_pad * 4 * 8);
                     hipLaunchKernelGGL(isk::radius_init_inline_kernel, dim3(1), dim3(isk::BLOCK), 0, h->stream,
-                                       h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)radius, h->d_queries.p, iq);
+                                       h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)jr, h->d_queries.p, iq);
                 } else
                 hipLaunchKernelGGL(isk::radius_init_kernel, dim3((nq_pad + isk::BLOCK - 1) / isk::BLOCK), dim3(isk::BLOCK), 0, h->stream,
-                                   h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)radius);
+                                   h->d_bias.p, h->d_cnt.p, nq, nq_pad, 0x7FFFFFFFu - (uint32_t)jr);
                 if ((rc = collect_from(0))) return rc;
                 launch_select(c.sl, nq);
                 HIPOK(hipGetLastError());
@@ -688,10 +713,11 @@ struct Batch {
             bp.counts = h->d_ghist.p;          // zeroed by the kernel: the running histogram of the levels / the counters of MODE_SELF
             bp.hint = isk::BOOT_NO_HINT;
             hist_live = true;
-            if (self && self_hint >= 0) {
+            const int job_hint = self_hint >= 0 ? self_hint : (radius_ratio >= 0 && ratio_starts_self ? ratio_bits(j) : -1);
+            if (self && job_hint >= 0) {
                 // the threshold a previous batch of this size ended at (+ margin) instead of a sample: no 65 536-row bootstrap, and
                 // the pass starts ~6 bits tighter -- without the flood of its first steps.  Verified by the caller.
-                bp.hint = (uint32_t)self_hint;
+                bp.hint = (uint32_t)job_hint;
                 used_hint = true;
                 hipLaunchKernelGGL(isk::boot_kernel, dim3(nq_pad), dim3(64), 0, h->stream, bp);
             } else if (nq_pad > 64 && h->boot_multi) {
@@ -1690,8 +1716,54 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             HIPOK(hipMemcpyAsync(h->p_block.p, h->d_block.p, bytes, hipMemcpyDeviceToHost, h->stream));
             return 0;
         };
+        // SEVERAL segments (an index of mixed code lengths -- what an ISCC-UNIT index is): the same speculation per segment.  The
+        // ordinary path costs boot + level + pick + collect + select per segment and two synchronisations (0.62 ms for one 256-bit
+        // query over 4 x 25 M rows); here every segment lists its rows within (hint + 1/32) x compared bits (radius_init + collect +
+        // select each), the lists are merged and ONE synchronisation brings results and flags.  The answer stands if no list
+        // overflowed, every query has k rows and its k-th NPHD is <= hint + 1/32: a row outside a segment's radius lies strictly
+        // beyond that ratio, a row inside it but not listed has k nearer rows of its own segment before it.
+        uint64_t total_rows = 0;
+        for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) total_rows += t.seg[b].n;
+        const bool mhintable = segments > 1 && radius < 0 && !out_freq && (m <= h->spec_max_queries || h->self_hint) && k <= total_rows;
+        bool mspec = mhintable && h->speculate && !h->spec_suppress && t.mhint(m, len).ready(k);
+        bool mspec_ok = false;
+        if (mspec) {
+            batch.radius_ratio = t.mhint(m, len).ratio + 1.0 / 32.0;      // the margin: 2 bits of 64, 8 of 256
+            batch.ratio_starts_self = m > h->spec_max_queries;             // larger batches: per-query thresholds from there on (see `hinted` below)
+        }
+        auto worst_ratio = [&]() -> double {                 // worst k-th NPHD of the merged lists; < 0: some query holds fewer than k rows
+            double worst = 0.0;
+            for (uint32_t i = 0; i < m; ++i) {
+                if (p_cnt[i] < k) return -1.0;
+                const isk::Record& r = p_rec[(size_t)i * k + k - 1];
+                worst = std::max(worst, r.prefix_bits ? (double)r.hamming / (double)r.prefix_bits : 0.0);
+            }
+            return worst;
+        };
         if ((rc = batch.begin(hq.data()))) return rc;
-        if (batch.multi) {
+        if (mspec && !batch.multi) {                        // (every non-empty segment is a job: cannot happen; never answer unverified)
+            mspec = false;
+            batch.radius_ratio = -1.0;
+            if ((rc = batch.begin(hq.data()))) return rc;
+        }
+        if (batch.multi && mspec) {
+            if ((rc = batch.merge())) return rc;
+            if ((rc = batch.copy_flags())) return rc;
+            if ((rc = copy_results())) return rc;
+            HIPOK(hipStreamSynchronize(h->stream));
+            const double worst = batch.any_flag() ? -1.0 : worst_ratio();
+            mspec_ok = worst >= 0.0 && worst <= batch.radius_ratio;        // (a row outside a radius lies beyond floor(ratio x bits) + 1 bits: strictly farther)
+            if (mspec_ok) { h->stats.spec_hits += 1; t.mhint(m, len).hit(worst); }
+            else {
+                h->stats.spec_misses += 1;
+                t.mhint(m, len).miss();
+                batch.radius_ratio = -1.0;
+                if ((rc = batch.begin(hq.data()))) return rc;
+            }
+        }
+        if (batch.multi && mspec_ok) {
+            // (answered above)
+        } else if (batch.multi) {
             // the per-segment lists must be complete before they are merged
             if ((rc = batch.copy_flags())) return rc;
             HIPOK(hipStreamSynchronize(h->stream));
@@ -1704,6 +1776,10 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             if ((rc = batch.merge())) return rc;
             if ((rc = copy_results())) return rc;
             HIPOK(hipStreamSynchronize(h->stream));
+            if (mhintable) {
+                const double worst = worst_ratio();
+                if (worst >= 0.0) t.mhint(m, len).seed(k, worst);
+            }
         } else if (speculate) {
             // SPECULATIVE single pass (small batches over one segment).  One query costs boot + level + pick + collect + select:
             // five launches for what is one pass over the rows (0.22 ms against a 0.13 ms pass).  The k-th distance of similar

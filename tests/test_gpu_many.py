@@ -400,3 +400,63 @@ def test_hints_are_kept_per_prefix_length(hip_engine):
                 assert ask(nq, 8) == (1, 0)
     finally:
         t.drop()
+
+
+def test_tables_of_several_code_lengths_speculate_per_segment(hip_engine):
+    """
+    An ISCC-UNIT index holds 64 / 128 / 192 / 256-bit codes in ONE NPHD table.  Small batches over it are first tried with every
+    segment listing its rows within (previous k-th NPHD) x compared bits + 2, merged and verified; near-duplicates, a query
+    inside a cluster that overflows one segment's list, and queries of another length (their own hint) -- all against the oracle.
+    """
+    from oracle import oracle_topk
+
+    rng = np.random.default_rng(8642)
+    n, k = 160_000, 10
+    lens = rng.choice([8, 16, 24, 32], size=n).astype(np.uint8)
+    words = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    centre = rng.integers(0, 2**64, size=4, dtype=np.uint64)
+    words[:30_000] = centre                                            # a cluster: 30 000 rows within a bit of `centre` ...
+    words[:30_000, 0] ^= np.uint64(1) << rng.integers(0, 64, size=30_000).astype(np.uint64)
+    lens[:30_000] = 32                                                 # ... all of them 256-bit codes
+    for j in range(4):
+        words[lens.astype(np.int64) <= 8 * j, j] = 0
+    keys = rng.permutation(n).astype(np.uint64) + np.uint64(1)
+    t = hip_engine.open_table(1, 1, 32)
+    try:
+        t.add(keys, words, lens)
+
+        def ask(q, nbytes):
+            q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, 4).copy()
+            q[:, (nbytes + 7) // 8 :] = 0
+            ql = np.full(len(q), nbytes, dtype=np.uint8)
+            before = hip_engine.stats()
+            got = t.search(q, ql, k)
+            after = hip_engine.stats()
+            exp = oracle_topk(1, keys, words, lens, q, ql, k)
+            for g, e, name in zip(got, exp, ("keys", "hamming", "prefix_bits", "count")):
+                np.testing.assert_array_equal(g, e, err_msg=name)
+            return after["spec_hits"] - before["spec_hits"], after["spec_misses"] - before["spec_misses"]
+
+        def rnd(nq):
+            return rng.integers(0, 2**64, size=(nq, 4), dtype=np.uint64)
+
+        for nq in (1, 5, 200):                                         # (200: above spec_max_queries -- every segment's single pass starts under the hint)
+            assert ask(rnd(nq), 32) == (0, 0)                          # seeds the hint of this size and length
+            assert ask(rnd(nq), 32) == (1, 0)
+            assert ask(rnd(nq), 16) == (0, 0)                          # 128-bit queries: their own hint
+            assert ask(rnd(nq), 16) == (1, 0)
+            near = words[rng.integers(30_000, n, size=nq)].copy()
+            near[:, 0] ^= np.uint64(5)
+            assert ask(near, 32) == (1, 0)                             # near-duplicates of stored codes of every length
+            assert ask(rnd(nq), 32) == (1, 0)
+        q = rnd(5)
+        q[2] = centre
+        assert ask(q, 32) == (0, 1)                                    # the 256-bit segment's list overflows: ordinary path
+        assert ask(rnd(5), 32) == (1, 0)
+        hip_engine.set_option("speculate", 0)
+        try:
+            assert ask(rnd(5), 32) == (0, 0)
+        finally:
+            hip_engine.set_option("speculate", 1)
+    finally:
+        t.drop()
