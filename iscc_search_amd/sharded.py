@@ -126,7 +126,7 @@ class ShardedTable:
         self.assets_share_a_rank = assets_share_a_rank
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # (batch-size class, k) -> [hint, batches still to skip, penalty]: the GLOBAL k-th distance the previous step of that shape
+        # (batch-size class, k, query lengths) -> [hint, batches still to skip, penalty]: the GLOBAL k-th distance the previous step of that shape
         # ended at + 2.  Every shard starts its pass under it (no bootstrap sample; the lists hold the shard's rows within the hint),
         # and the step stands if every merged list holds k rows -- they all lie within the hint, so nothing nearer was left out.
         # The merged lists are the same on every rank, hence so is every decision taken from them.
@@ -200,7 +200,8 @@ class ShardedTable:
         alone = self.world_size == 1 and not (self.always_gather and self.dist.is_initialized())
         state = None
         if self.use_hints and max_hamming is None and nq and not alone:
-            state = self._hints.setdefault((int(nq).bit_length(), int(k)), [None, 0, 0])
+            qlen = None if q_nbytes is None else tuple(sorted(set(int(b) for b in np.asarray(q_nbytes))))      # (a prefix length has its own distances)
+            state = self._hints.setdefault((int(nq).bit_length(), int(k), qlen), [None, 0, 0])
             if state[0] is not None and state[1] == 0:
                 out = self._exchange(q_words, q_nbytes, k, None, {"hint": state[0]})
                 cnt = out[3]

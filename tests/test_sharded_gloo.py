@@ -265,7 +265,7 @@ def _hint_worker(rank, world, port, out_dir):
         ask(random_q[nq : 2 * nq])    # 1: every shard starts under it; the merged lists hold k rows: stands
         ask(near_q)                   # 1: far inside the hint (which decays by one bit)
         ask(random_q[2 * nq : 3 * nq])   # 1
-        sharded._hints[(int(nq).bit_length(), k)][0] = 3    # a hint that is too tight for random queries ...
+        sharded._hints[(int(nq).bit_length(), k, None)][0] = 3    # a hint that is too tight for random queries ...
         ask(random_q[3 * nq :])       # 1: ... the merged lists come up short: the step is repeated without it (and re-seeds)
         ask(random_q[:nq])            # 1: one miss does not back off
         assert log == [0, 1, 1, 1, 1, 1], log
