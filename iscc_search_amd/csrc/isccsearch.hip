@@ -485,7 +485,9 @@ struct Batch {
     Batch(H* h_, Table& t_, uint32_t nq_, uint32_t qbytes_, uint32_t k_, isk::Record* out, uint32_t* out_cnt)
         : h(h_), t(t_), nq(nq_), qbytes(qbytes_), k(k_), d_out(out), d_out_cnt(out_cnt) {}
 
-    int ratio_bits(const Job& j) const { const int bits = 8 * (int)j.pbytes; return std::min(bits, (int)std::floor(radius_ratio * bits)); }
+    // (+ 1e-9: a product within rounding of an integer counts as that integer, so that a row outside the radius lies beyond the
+    //  ratio by >= 1e-9 / bits -- orders of magnitude more than the rounding of the k-th distance the caller compares with it)
+    int ratio_bits(const Job& j) const { const int bits = 8 * (int)j.pbytes; return std::min(bits, (int)std::floor(radius_ratio * bits + 1e-9)); }
     // the fixed threshold of a job's range-limited pass, or -1
     int job_radius(const Job& j) const {
         if (radius >= 0) return radius;
