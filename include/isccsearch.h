@@ -227,6 +227,43 @@ int isccsearch_doc_freq_counted(isccsearch_handle* h, uint32_t table, uint32_t n
 int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const uint64_t* keys,
                         uint32_t dup_limit, uint32_t* out_freq);
 
+/* Simprint search WITH its asset scoring, on the device: what UsearchSimprintIndex.search_raw does in one call
+ * (iscc_search/indexes/simprint/usearch_core.py:137-269) -- the oversampled batched neighbour search (:161-165, `count` =
+ * limit x oversampling neighbours per query simprint; max_hamming >= 0 lists the rows within that radius instead, see
+ * isccsearch_search_within), then on the neighbour lists as they lie in device memory: the match threshold on
+ * score = 1 - distance / ndim (:182-184), the best chunk per (asset, query simprint) in the reference's visiting order
+ * (:175-196; the asset is the first word of the 128-bit chunk-pointer key), the IDF-weighted mean per asset in the
+ * reference's ORDER of float64 additions (:215-236, idf = log(1 + total_assets / (1 + freq)), lmdb_ops.py:67-81, with log()
+ * of the host libm), order (-score, asset) and the cut to `limit` (:268-269).  Only the <= limit winners (and, when
+ * out_chunks is given, their matched chunks: `detailed`, :238-255) leave the device.
+ *   dup_limit > 0   document frequencies are the device's: of a matched STORED simprint from the table's frequency column
+ *                   (isccsearch_get_freq), of an unmatched QUERY simprint the distinct assets among its first dup_limit
+ *                   collisions (isccsearch_doc_freq) -- what the reference's doc_freq_fn computes with an LMDB cursor walk
+ *                   (usearch/index.py:1395-1403, lmdb_ops.py:139-166)
+ *   dup_limit == 0  every frequency is 1 (the reference's doc_freq_fn = None, :204-211)
+ * 128-bit-key Hamming tables only.  out_results[limit]; out_chunks[limit * nq] and out_chunk_words[limit * nq * max_words]
+ * (both or neither; chunks of result r are out_chunks[first_chunk .. first_chunk + matches), ascending query index, words =
+ * the STORED simprint); out_info[4] = {results written, assets matched, longest neighbour list (what a caller that asked for
+ * a radius compares with `count` to see a list that filled the cap), chunks written}. */
+typedef struct isccsearch_simprint_result {
+    uint64_t asset;        /* first key word: ISCC-ID body */
+    double   score;
+    uint32_t matches;      /* query simprints matched by this asset */
+    uint32_t first_chunk;  /* index of its first entry in out_chunks */
+} isccsearch_simprint_result;
+typedef struct isccsearch_simprint_chunk {
+    uint64_t key_lo;       /* second key word: offset (high 32 bits) | size (low 32 bits) */
+    uint32_t query;        /* index of the query simprint */
+    uint32_t hamming;      /* differing bits: score = 1 - hamming / ndim */
+    uint32_t freq;         /* document frequency of the stored simprint (1 when dup_limit == 0) */
+    uint32_t reserved;
+} isccsearch_simprint_chunk;
+int isccsearch_simprint_score(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                              uint32_t count, int32_t max_hamming, double threshold, uint32_t limit,
+                              int64_t total_assets, uint32_t dup_limit,
+                              isccsearch_simprint_result* out_results, isccsearch_simprint_chunk* out_chunks,
+                              uint64_t* out_chunk_words, uint32_t* out_info);
+
 /* Multi-GPU building blocks (row-range shards, one process per GPU).
  * search_device: same search, results left in caller-provided DEVICE memory
  *   d_records[nq*k] (isccsearch_record), d_counts[nq]; queries must share one byte length.

@@ -36,6 +36,7 @@
 #include "kernels.hip.h"
 #include "mfma_scan.h"
 #include "docfreq.h"
+#include "simprint_score.h"
 #include "keymap.h"
 
 namespace {
@@ -243,6 +244,17 @@ struct isccsearch_handle {
     DevBuf<uint64_t> d_misc2;
     std::vector<isk::Record> h_final;
     std::vector<uint32_t> h_cnt, h_overflow;
+    // isccsearch_simprint_score: the neighbour lists of one request stay on the device with their rows; simprint_score.hip's buffers
+    DevBuf<isk::Record> d_sp_rec;
+    DevBuf<uint32_t> d_sp_rows, d_sp_nbest, d_sp_offs, d_sp_freqq, d_sp_unknown, d_sp_entry[2], d_sp_order[2], d_sp_matches, d_sp_nassets;
+    DevBuf<unsigned char> d_sp_best, d_sp_temp;
+    DevBuf<uint64_t> d_sp_asset[2];
+    DevBuf<double> d_sp_score[2], d_sp_tab;
+    PinBuf<double> p_sp_tab;
+    PinBuf<unsigned char> p_sp_out;
+    // the similarity / IDF tables on the device are those of (bits, total_assets, dup_limit):
+    uint32_t sp_tab_bits = 0, sp_tab_dup = 0xFFFFFFFFu;
+    int64_t sp_tab_total = -1;
     // profiling
     // asynchronous device searches: "results ready" for the consumer stream, "query upload done" for the pinned staging
     hipEvent_t ev_done = nullptr, ev_staged = nullptr, ev_producer = nullptr;
@@ -343,6 +355,22 @@ int ensure_index(H* h, Table& t) {
         }
     }
     t.indexed = true;
+    return 0;
+}
+
+// the segment's document-frequency column (docfreq.hip), (re)built when rows changed since it was made
+int ensure_freq_column(H* h, Table& t, Segment& s, uint32_t dup_limit) {
+    if (s.freq_rows == s.n && s.freq_dup == dup_limit && s.freq) return 0;
+    if (s.freq) { (void)hipFree(s.freq); s.freq = nullptr; }
+    s.freq_rows = 0;
+    hipError_t e = hipMalloc((void**)&s.freq, s.n * sizeof(uint32_t));
+    if (e != hipSuccess) { s.freq = nullptr; (void)hipGetLastError(); return fail(-ENOMEM, "hipMalloc(frequency column, %llu bytes) failed: %s", (unsigned long long)s.n * 4, hipGetErrorString(e)); }
+    std::string err;
+    int rc;
+    if ((rc = iskdf::build_freq_column(s.col, (int)s.W, s.keys, t.key_words, s.n, dup_limit, s.freq, h->stream, &err))) return fail(rc, "%s", err.c_str());
+    s.freq_rows = s.n;
+    s.freq_dup = dup_limit;
+    h->stats.freq_builds += 1;
     return 0;
 }
 
@@ -466,6 +494,8 @@ struct Batch {
     uint32_t nq, qbytes, k;
     isk::Record* d_out;       // [nq*k]   device
     uint32_t* d_out_cnt;      // [nq]     device
+    uint32_t* d_out_rows = nullptr;   // [nq*k] when set, select_kernel also leaves the segment row of every record (simprint scoring)
+    uint32_t* d_out_kth = nullptr;    // [nq]   when set, ... and the hamming distance of every query's last result
     int tq = 8;
     int radius = -1;          // >= 0: report only rows within this Hamming distance (fixed threshold, no sampling)
     double radius_ratio = -1.0;   // >= 0 (speculative pass over SEVERAL segments): per segment, rows within ratio x compared bits
@@ -512,10 +542,15 @@ struct Batch {
         c.sl.overflow = d_flags + ji * (size_t)nq_pad;
         c.sl.k = k; c.sl.P = P; c.sl.prefix_bits = j.pbytes * 8; c.sl.q_base = 0;
         c.sl.overflow_count = mark_overflow ? isk::COUNT_OVERFLOW : 0;
+        c.sl.out_rows = multi ? nullptr : d_out_rows;
+        c.sl.out_kth = multi ? nullptr : d_out_kth;
         return c;
     }
     void launch_select(const isk::SelectParams& sl, uint32_t blocks) const {
-        if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+        if (sl.out_rows) {
+            if (t.key_words == 2) hipLaunchKernelGGL((isk::select_kernel<2, true>), dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+            else hipLaunchKernelGGL((isk::select_kernel<1, true>), dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+        } else if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
         else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
     }
     size_t flag_words() const { return jobs.size() * (size_t)nq_pad; }
@@ -588,7 +623,7 @@ struct Batch {
         if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0 && radius_ratio < 0) cap = std::max<uint32_t>(cap, 64 * k);
         multi = jobs.size() > 1;
         P = next_pow2(std::max<uint32_t>(k, 1024));   // select's LDS sort buffer: room for small tie classes (12-20 KB)
-        sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words;
+        sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words + (d_out_rows ? (size_t)P * 4 : 0);
         int rc;
         if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;
         if ((rc = h->d_bias.ensure(nq_pad))) return rc;
@@ -1106,6 +1141,8 @@ int isccsearch_create(int device_id, isccsearch_handle** out) {
     // the select kernel may need more than the default dynamic LDS for k near ISCCSEARCH_MAX_K
     HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(&isk::select_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(&isk::select_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(&isk::select_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(&isk::select_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     h->stats.queries_per_pass = h->tq;
     h->stats.compute_units = h->cus;
     *out = h.release();
@@ -1126,6 +1163,10 @@ int isccsearch_destroy(isccsearch_handle* h) {
         h->d_lists.release(); h->d_final.release(); h->d_misc.release(); h->d_misc2.release();
         h->p_queries.release(); h->p_flags.release();
         h->d_block.release(); h->p_block.release();
+        h->d_sp_rec.release(); h->d_sp_rows.release(); h->d_sp_nbest.release(); h->d_sp_offs.release(); h->d_sp_freqq.release();
+        h->d_sp_unknown.release(); h->d_sp_matches.release(); h->d_sp_nassets.release(); h->d_sp_best.release(); h->d_sp_temp.release();
+        for (int i = 0; i < 2; ++i) { h->d_sp_entry[i].release(); h->d_sp_order[i].release(); h->d_sp_asset[i].release(); h->d_sp_score[i].release(); }
+        h->d_sp_tab.release(); h->p_sp_tab.release(); h->p_sp_out.release();
         if (h->d_rank) (void)hipFree(h->d_rank);
         for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         for (hipEvent_t e : {h->ev_done, h->ev_staged, h->ev_producer}) if (e) (void)hipEventDestroy(e);
@@ -1606,17 +1647,7 @@ int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const 
     for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) {
         if (rows[b].empty()) continue;
         Segment& s = t.seg[b];
-        if (s.freq_rows != s.n || s.freq_dup != dup_limit) {
-            if (s.freq) { (void)hipFree(s.freq); s.freq = nullptr; }
-            s.freq_rows = 0;
-            hipError_t e = hipMalloc((void**)&s.freq, s.n * sizeof(uint32_t));
-            if (e != hipSuccess) { s.freq = nullptr; (void)hipGetLastError(); return fail(-ENOMEM, "hipMalloc(frequency column, %llu bytes) failed: %s", (unsigned long long)s.n * 4, hipGetErrorString(e)); }
-            std::string err;
-            if ((rc = iskdf::build_freq_column(s.col, (int)s.W, s.keys, KW, s.n, dup_limit, s.freq, h->stream, &err))) return fail(rc, "%s", err.c_str());
-            s.freq_rows = s.n;
-            s.freq_dup = dup_limit;
-            h->stats.freq_builds += 1;
-        }
+        if ((rc = ensure_freq_column(h, t, s, dup_limit))) return rc;
         const uint64_t m = rows[b].size();
         if ((rc = h->d_misc.ensure(m))) return rc;
         if ((rc = h->d_freq.ensure(m))) return rc;
@@ -1632,13 +1663,25 @@ int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const 
     return 0;
 }
 
+// isccsearch_simprint_score: where a search leaves its lists for the scoring kernels instead of handing them to the host
+struct ScoreSink {
+    isksp::Buffers buf{};
+    int h_max = -1;
+    uint32_t dup_limit = 0;
+    uint32_t entries = 0;       // best (asset, query) entries appended so far -- known after each batch's synchronisation
+    uint32_t max_count = 0;     // longest neighbour list
+    bool unknown_any = false;   // some query's own document frequency could not be read off its list
+};
+
 // The search itself; h->mu is held by the caller.
 //   radius >= 0   range-limited search (fixed threshold)
 //   out_freq      when set, only the number of distinct assets per result list is returned (doc frequency)
+//   sink          when set (one-segment Hamming tables), records and rows stay in the sink's device buffers, every batch is followed by
+//                 the marking / compaction kernels of simprint_score.hip, and only {counts | flags | k-th distances | info} reach the host
 static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                          const uint8_t* q_nbytes, uint32_t k,
                          uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count,
-                         int radius = -1, uint32_t* out_freq = nullptr, uint32_t* out_collisions = nullptr) {
+                         int radius = -1, uint32_t* out_freq = nullptr, uint32_t* out_collisions = nullptr, ScoreSink* sink = nullptr) {
     Table* tp;
     int rc = get_table(h, table, tp);
     if (rc) return rc;
@@ -1665,10 +1708,11 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         for (uint32_t i = 0; i < m; ++i)
             memcpy(&hq[(size_t)i * t.max_words], q_words + (size_t)order[pos + i] * t.max_words, (size_t)t.max_words * 8);
         // result block {records [m][k] | counts [m] | flags [<= m + 15]} on the device and, mirrored, in pinned memory
-        const size_t rec_bytes = (size_t)m * k * sizeof(isk::Record);
+        const size_t rec_bytes = sink ? 0 : (size_t)m * k * sizeof(isk::Record);     // (a sink keeps the records on the device)
         const size_t flag_slots = (size_t)m + 16;                       // nq_pad <= m + 15 for every T_q
-        // (+ m counts behind the flags when a document-frequency call also wants the lists' lengths)
-        const size_t block_bytes = rec_bytes + ((size_t)m + flag_slots + (out_collisions ? m : 0)) * sizeof(uint32_t);
+        // (+ m counts behind the flags when a document-frequency call also wants the lists' lengths;
+        //  + m k-th distances and the scoring kernels' info words when the lists stay on the device)
+        const size_t block_bytes = rec_bytes + ((size_t)m + flag_slots + (out_collisions || sink ? m : 0) + (sink ? isksp::INFO_WORDS : 0)) * sizeof(uint32_t);
         if ((rc = h->d_block.ensure(block_bytes))) return rc;
         if ((rc = h->p_block.ensure(block_bytes))) return rc;
         const isk::Record* const p_rec = reinterpret_cast<const isk::Record*>(h->p_block.p);
@@ -1680,11 +1724,13 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         // into the device's address space), so the host only synchronises.  A device->host copy costs ~25 us of queue
         // hand-over after the kernel, more than the 240 bytes per query take to cross PCIe as plain stores.  Large blocks
         // (big k x many queries) keep the DMA copy.
-        const bool direct = one_copy && block_bytes <= DIRECT_RESULT_BYTES;
-        isk::Record* const d_rec = reinterpret_cast<isk::Record*>(direct ? h->p_block.p : h->d_block.p);
+        const bool direct = one_copy && block_bytes <= DIRECT_RESULT_BYTES && !sink;
+        isk::Record* const d_rec = sink ? h->d_sp_rec.p + (size_t)pos * k : reinterpret_cast<isk::Record*>(direct ? h->p_block.p : h->d_block.p);
         uint32_t* const d_cnt = reinterpret_cast<uint32_t*>((direct ? h->p_block.p : h->d_block.p) + rec_bytes);
+        uint32_t* const p_kth = p_cnt + m + flag_slots;                  // (sink) hamming of every query's last result
         Batch batch(h, t, m, len, k, d_rec, d_cnt);
         batch.radius = radius;
+        if (sink) { batch.d_out_rows = h->d_sp_rows.p + (size_t)pos * k; batch.d_out_kth = d_cnt + m + flag_slots; }
         if (one_copy) { batch.d_flags = d_cnt + m; batch.h_flags = p_cnt + m; }
         // (see the speculative branch below) eligible: an ordinary top-k search of a small batch over ONE segment that has been
         // searched with this k before
@@ -1714,6 +1760,15 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 return 0;
             }
             if (direct) return 0;                                  // already written where the host reads it
+            if (sink) {
+                // the lists are final on the device (or will be redone and this queued again): mark the best chunk of every
+                // (asset, query), append them to the request's entry list; the host gets counts, flags, k-th distances and info
+                uint32_t* const d_info = d_cnt + m + flag_slots + m;
+                isksp::BatchArgs ba{pos, m, k, d_cnt, sink->h_max, sink->dup_limit, sink->entries, d_info};
+                HIPOK(isksp::queue_batch(sink->buf, ba, h->stream));
+                HIPOK(hipMemcpyAsync(h->p_block.p, h->d_block.p, block_bytes, hipMemcpyDeviceToHost, h->stream));
+                return 0;
+            }
             const size_t bytes = rec_bytes + (size_t)m * sizeof(uint32_t) + (one_copy ? batch.flag_words() * sizeof(uint32_t) : 0);
             HIPOK(hipMemcpyAsync(h->p_block.p, h->d_block.p, bytes, hipMemcpyDeviceToHost, h->stream));
             return 0;
@@ -1860,9 +1915,19 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
             // step at these distances, so the margin costs a handful of candidates and absorbs the spread between queries)
             uint32_t worst = 0;
             for (uint32_t i = 0; i < m; ++i)
-                if (p_cnt[i]) worst = std::max<uint32_t>(worst, p_rec[(size_t)i * k + p_cnt[i] - 1].hamming);
+                if (p_cnt[i]) worst = std::max<uint32_t>(worst, sink ? p_kth[i] : p_rec[(size_t)i * k + p_cnt[i] - 1].hamming);
             if (spec_ok) spec_seg->hint(m, len).hit(worst);
             else spec_seg->hint(m, len).seed(k, worst);
+        }
+        if (sink) {
+            if (!batch.jobs.empty()) {
+                const uint32_t* p_info = p_kth + m;
+                sink->entries = p_info[0];
+                sink->unknown_any = sink->unknown_any || p_info[1] != 0;
+                for (uint32_t i = 0; i < m; ++i) sink->max_count = std::max(sink->max_count, std::min(p_cnt[i], k));
+            }
+            pos = end;
+            continue;
         }
         if (out_freq) {
             if (batch.jobs.empty()) for (uint32_t i = 0; i < m; ++i) out_freq[order[pos + i]] = 0;
@@ -2169,6 +2234,146 @@ int isccsearch_doc_freq_counted(isccsearch_handle* h, uint32_t table, uint32_t n
     std::lock_guard<std::mutex> lk(h->mu);
     h->stats.searches += 1;
     return search_locked(h, table, nq, q_words, q_nbytes, dup_limit, nullptr, nullptr, nullptr, nullptr, 0, out_freq, out_collisions);
+}
+
+// Search + asset scoring with the neighbour lists kept on the device (usearch_core.py:137-269); see include/isccsearch.h.
+int isccsearch_simprint_score(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
+                              uint32_t count, int32_t max_hamming, double threshold, uint32_t limit,
+                              int64_t total_assets, uint32_t dup_limit,
+                              isccsearch_simprint_result* out_results, isccsearch_simprint_chunk* out_chunks,
+                              uint64_t* out_chunk_words, uint32_t* out_info) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (count < 1) return fail(-EINVAL, "`count` must be >= 1");
+    if (count > ISCCSEARCH_MAX_K) return fail(-EINVAL, "count %u exceeds ISCCSEARCH_MAX_K (%d)", count, ISCCSEARCH_MAX_K);
+    if (max_hamming > 256) return fail(-EINVAL, "max_hamming %d exceeds 256", max_hamming);
+    if (dup_limit > ISCCSEARCH_MAX_K) return fail(-EINVAL, "dup_limit %u exceeds ISCCSEARCH_MAX_K (%d)", dup_limit, ISCCSEARCH_MAX_K);
+    if (limit < 1) return fail(-EINVAL, "limit must be >= 1");
+    if (!out_info) return fail(-EINVAL, "NULL argument");
+    out_info[0] = out_info[1] = out_info[2] = out_info[3] = 0;
+    if (nq == 0) return 0;
+    if (!q_words || !out_results || (out_chunks == nullptr) != (out_chunk_words == nullptr)) return fail(-EINVAL, "NULL argument");
+    if ((uint64_t)nq * count > 0xFFFFFFFFull) return fail(-E2BIG, "%u query simprints x %u neighbours exceed 2^32 entries", nq, count);
+    if (!(threshold == threshold)) return fail(-EINVAL, "threshold is not a number");
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    if (t.metric != ISCCSEARCH_METRIC_HAMMING || t.key_words != 2)
+        return fail(-EINVAL, "simprint scoring is defined for fixed-length (Hamming) tables with 128-bit chunk-pointer keys");
+    Segment& s = t.seg[t.max_bytes];
+    if (s.n == 0) return 0;
+    if (s.n > 0xFFFFFFFFull) return fail(-E2BIG, "simprint scoring addresses rows with 32 bits; the table holds %llu", (unsigned long long)s.n);
+    HIPOK(hipSetDevice(h->device));
+    h->stats.searches += 1;
+    const uint32_t k = count, bits = 8 * (uint32_t)t.max_bytes;
+    // the match threshold on the integer distance: score = 1.0 - distance / ndim (usearch_core.py:182) falls with the distance, so
+    // the largest distance whose score -- in this very arithmetic -- still passes is found once
+    int h_max = -1;
+    for (uint32_t d = 0; d <= bits; ++d) {
+        if (1.0 - (double)d / (double)bits >= threshold) h_max = (int)d;
+        else break;
+    }
+    if (dup_limit && (rc = ensure_freq_column(h, t, s, dup_limit))) return rc;
+    // similarity and IDF values come from the HOST's arithmetic (log() of libm is what CPython's math.log calls; lmdb_ops.py:67-81)
+    const uint32_t n_idf = dup_limit + 1;
+    if (h->sp_tab_bits != bits || h->sp_tab_dup != dup_limit || h->sp_tab_total != total_assets) {
+        const size_t words = (size_t)bits + 1 + n_idf;
+        if ((rc = h->p_sp_tab.ensure(words))) return rc;
+        if ((rc = h->d_sp_tab.ensure(words))) return rc;
+        HIPOK(hipStreamSynchronize(h->stream));      // (a previous upload may still be reading the staging block)
+        double* tab = h->p_sp_tab.p;
+        for (uint32_t d = 0; d <= bits; ++d) tab[d] = 1.0 - (double)d / (double)bits;
+        auto idf = [&](uint32_t freq) { return total_assets <= 0 ? 0.0 : std::log(1.0 + (double)total_assets / (double)(1 + (uint64_t)freq)); };
+        if (dup_limit) for (uint32_t f = 0; f <= dup_limit; ++f) tab[bits + 1 + f] = idf(f);
+        else tab[bits + 1] = idf(1);
+        HIPOK(hipMemcpyAsync(h->d_sp_tab.p, tab, words * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->sp_tab_bits = bits; h->sp_tab_dup = dup_limit; h->sp_tab_total = total_assets;
+    }
+    const size_t slots = (size_t)nq * k;
+    if ((rc = h->d_sp_rec.ensure(slots))) return rc;
+    if ((rc = h->d_sp_rows.ensure(slots))) return rc;
+    if ((rc = h->d_sp_best.ensure(slots))) return rc;
+    if ((rc = h->d_sp_nbest.ensure(nq))) return rc;
+    if ((rc = h->d_sp_offs.ensure(nq))) return rc;
+    if ((rc = h->d_sp_freqq.ensure(nq))) return rc;
+    if ((rc = h->d_sp_unknown.ensure(nq))) return rc;
+    if ((rc = h->d_sp_nassets.ensure(1))) return rc;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = h->d_sp_asset[i].ensure(slots))) return rc;
+        if ((rc = h->d_sp_entry[i].ensure(slots))) return rc;
+    }
+    ScoreSink sink;
+    sink.h_max = h_max;
+    sink.dup_limit = dup_limit;
+    auto bind = [&]() {
+        isksp::Buffers& b = sink.buf;
+        b.rec = reinterpret_cast<const isccsearch_record*>(h->d_sp_rec.p);
+        b.rows = h->d_sp_rows.p; b.best = h->d_sp_best.p; b.nbest = h->d_sp_nbest.p; b.offs = h->d_sp_offs.p;
+        b.freq_q = h->d_sp_freqq.p; b.unknown = h->d_sp_unknown.p; b.n_assets = h->d_sp_nassets.p;
+        for (int i = 0; i < 2; ++i) {
+            b.c_asset[i] = h->d_sp_asset[i].p; b.c_entry[i] = h->d_sp_entry[i].p;
+            b.score[i] = h->d_sp_score[i].p; b.order[i] = h->d_sp_order[i].p;
+        }
+        b.matches = h->d_sp_matches.p;
+        b.temp = h->d_sp_temp.p; b.temp_bytes = h->d_sp_temp.n;
+    };
+    bind();
+    if ((rc = search_locked(h, table, nq, q_words, nullptr, k, nullptr, nullptr, nullptr, nullptr, max_hamming < 0 ? -1 : max_hamming, nullptr, nullptr, &sink))) return rc;
+    out_info[2] = sink.max_count;
+    const uint32_t entries = sink.entries;
+    if (entries == 0) return 0;
+    if (sink.unknown_any) {
+        // rare: a query simprint with k equal stored rows and k < dup_limit -- its document frequency needs the collision scan
+        std::vector<uint32_t> unk(nq), fq(nq);
+        HIPOK(hipMemcpyAsync(unk.data(), h->d_sp_unknown.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipMemcpyAsync(fq.data(), h->d_sp_freqq.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        std::vector<uint32_t> which;
+        for (uint32_t q = 0; q < nq; ++q) if (unk[q]) which.push_back(q);
+        std::vector<uint64_t> qw(which.size() * (size_t)t.max_words);
+        for (size_t i = 0; i < which.size(); ++i) memcpy(&qw[i * t.max_words], q_words + (size_t)which[i] * t.max_words, (size_t)t.max_words * 8);
+        std::vector<uint32_t> freq(which.size());
+        if ((rc = search_locked(h, table, (uint32_t)which.size(), qw.data(), nullptr, dup_limit, nullptr, nullptr, nullptr, nullptr, 0, freq.data()))) return rc;
+        for (size_t i = 0; i < which.size(); ++i) fq[which[i]] = freq[i];
+        HIPOK(hipMemcpyAsync(h->d_sp_freqq.p, fq.data(), (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));       // (fq leaves scope)
+    }
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = h->d_sp_score[i].ensure(entries))) return rc;
+        if ((rc = h->d_sp_order[i].ensure(entries))) return rc;
+    }
+    if ((rc = h->d_sp_matches.ensure(entries))) return rc;
+    if ((rc = h->d_sp_temp.ensure(isksp::sort_temp_bytes(entries)))) return rc;
+    bind();
+    // outputs in pinned memory, written by the emit kernel itself: {info[4] | results[limit] | chunks | chunk words}
+    const uint32_t W = (uint32_t)t.max_words;
+    const size_t res_off = 16, chunk_off = res_off + (size_t)limit * sizeof(isccsearch_simprint_result);
+    const size_t chunk_cap = out_chunks ? (size_t)std::min<uint64_t>((uint64_t)limit * nq, entries) : 0;
+    const size_t words_off = chunk_off + chunk_cap * sizeof(isccsearch_simprint_chunk);
+    if ((rc = h->p_sp_out.ensure(words_off + chunk_cap * W * 8))) return rc;
+    unsigned char* const po = h->p_sp_out.p;
+    isksp::ScoreArgs sa{};
+    sa.nq = nq; sa.k = k; sa.entries = entries; sa.limit = limit;
+    sa.sim_tab = h->d_sp_tab.p; sa.idf_tab = h->d_sp_tab.p + bits + 1; sa.dup_limit = dup_limit;
+    sa.freq_col = dup_limit ? s.freq : nullptr;
+    for (uint32_t w = 0; w < s.W; ++w) sa.col[w] = s.col[w];
+    sa.W = W;
+    sa.out_info = reinterpret_cast<uint32_t*>(po);
+    sa.out_results = reinterpret_cast<isccsearch_simprint_result*>(po + res_off);
+    sa.out_chunks = out_chunks ? reinterpret_cast<isccsearch_simprint_chunk*>(po + chunk_off) : nullptr;
+    sa.out_chunk_words = out_chunks ? reinterpret_cast<uint64_t*>(po + words_off) : nullptr;
+    HIPOK(isksp::queue_score(sink.buf, sa, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    const uint32_t* info = reinterpret_cast<const uint32_t*>(po);
+    const uint32_t n = info[0];
+    out_info[0] = n; out_info[1] = info[1]; out_info[3] = info[3];
+    memcpy(out_results, po + res_off, (size_t)n * sizeof(isccsearch_simprint_result));
+    if (out_chunks) {
+        memcpy(out_chunks, po + chunk_off, (size_t)info[3] * sizeof(isccsearch_simprint_chunk));
+        memcpy(out_chunk_words, po + words_off, (size_t)info[3] * W * 8);
+    }
+    return 0;
 }
 
 static int search_device_impl(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,

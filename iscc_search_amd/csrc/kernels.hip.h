@@ -778,7 +778,9 @@ __global__ __launch_bounds__(BLOCK) void pick_kernel(const PickParams p) {
 //   2. tie class h == h*: MSB-first radix select on the key (8 bits per pass) until the r smallest
 //      keys of the class are pinned down
 //   3. compact the keff winners into LDS, bitonic sort by (hamming, key_hi, key_lo), emit records
-// dynamic LDS: sh[P] u32 | pad | klo[P] u64 | khi[P] u64 (KW == 2)
+// dynamic LDS: sh[P] u32 | pad | klo[P] u64 | khi[P] u64 (KW == 2) | row[P] u32 (ROWS)
+// ROWS: the segment row of every result travels through the sort and is written beside the records (out_rows) -- the
+// simprint scoring kernels (simprint_score.hip) read the stored code and its document frequency by row, not by key.
 // ---------------------------------------------------------------------------------------------
 struct SelectParams {
     const uint32_t* cnt;      // [nq_pad * CNT_STRIDE]
@@ -795,6 +797,9 @@ struct SelectParams {
     uint32_t q_base;          // block b serves query q_base + b
     uint32_t overflow_count;  // what out_count[q] becomes when the candidate list overflowed: 0, or COUNT_OVERFLOW for callers
                               // that cannot look at the flags before the results travel on (search_device_async)
+    uint32_t* out_rows;       // [nq][k] segment row of every record (select_kernel<KW, true> only)
+    uint32_t* out_kth;        // nullable [nq]: hamming of the query's LAST result (0 when it has none) -- what the host needs of a
+                              // result block that stays on the device to seed the next batch's threshold hint
 };
 
 template <int KW>
@@ -821,7 +826,7 @@ __device__ __forceinline__ void key_top(uint64_t hi, uint64_t lo, int d, uint64_
     }
 }
 
-template <int KW>
+template <int KW, bool ROWS = false>
 __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t hist[320];
@@ -831,19 +836,20 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
     uint32_t* sh = reinterpret_cast<uint32_t*>(smem);
     uint64_t* sklo = reinterpret_cast<uint64_t*>(smem + (((size_t)P * 4 + 15) & ~(size_t)15));
     uint64_t* skhi = sklo + P;   // only touched when KW == 2
+    uint32_t* srow = reinterpret_cast<uint32_t*>(sklo + (size_t)P * KW);   // only touched when ROWS
 
     const uint32_t tid = threadIdx.x;
     const uint32_t q = p.q_base + blockIdx.x;
     const uint32_t total = p.cnt[(uint64_t)q * CNT_STRIDE];
     if (tid == 0) p.overflow[q] = total > p.cap ? 1u : 0u;   // always written: the host never has to clear the flags
     if (total > p.cap) {             // candidate list overflowed: host reruns this query exactly
-        if (tid == 0) p.out_count[q] = p.overflow_count;
+        if (tid == 0) { p.out_count[q] = p.overflow_count; if (p.out_kth) p.out_kth[q] = 0; }
         return;
     }
     const uint64_t* cand = p.cand + (uint64_t)q * p.cap;
     const uint32_t keff = p.k < total ? p.k : total;
     if (keff == 0) {
-        if (tid == 0) p.out_count[q] = 0;
+        if (tid == 0) { p.out_count[q] = 0; if (p.out_kth) p.out_kth[q] = 0; }
         return;
     }
 
@@ -902,7 +908,7 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
             if (thi > phi || (thi == phi && tlo > plo)) continue;
         }
         const uint32_t pos = atomicAdd(&n_out, 1u);
-        if (pos < P) { sh[pos] = h; sklo[pos] = klo; if (KW == 2) skhi[pos] = khi; }
+        if (pos < P) { sh[pos] = h; sklo[pos] = klo; if (KW == 2) skhi[pos] = khi; if (ROWS) srow[pos] = (uint32_t)(c & 0xFFFFFFFFFFFFULL); }
     }
     __syncthreads();
     const uint32_t got = n_out < P ? n_out : P;     // == keff when keys are unique
@@ -928,6 +934,7 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
                     sh[lo_i] = hb; sh[hi_i] = ha;
                     sklo[lo_i] = lb; sklo[hi_i] = la;
                     if (KW == 2) { skhi[lo_i] = kb; skhi[hi_i] = ka; }
+                    if (ROWS) { const uint32_t ra = srow[lo_i]; srow[lo_i] = srow[hi_i]; srow[hi_i] = ra; }
                 }
             }
             __syncthreads();
@@ -942,8 +949,9 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const SelectParams p) {
         rec.hamming = (uint16_t)sh[i];
         rec.prefix_bits = (uint16_t)p.prefix_bits;
         p.out[(uint64_t)q * p.k + i] = rec;
+        if (ROWS) p.out_rows[(uint64_t)q * p.k + i] = srow[i];
     }
-    if (tid == 0) p.out_count[q] = nres;
+    if (tid == 0) { p.out_count[q] = nres; if (p.out_kth) p.out_kth[q] = nres ? sh[nres - 1] : 0; }
 }
 
 // ---------------------------------------------------------------------------------------------

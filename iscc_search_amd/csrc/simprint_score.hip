@@ -1,0 +1,355 @@
+// Simprint asset scoring on the device: see simprint_score.h for the pipeline and the reference lines it restates
+// (iscc_search/indexes/simprint/usearch_core.py:171-269).  Built for gfx950 only.
+#include <cstring>   // rocPRIM's texture iterator calls memset without including it
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "simprint_score.h"
+
+namespace isksp {
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr uint64_t EMPTY = ~0ULL;
+constexpr uint32_t COUNT_OVERFLOW = ISCCSEARCH_COUNT_OVERFLOW;
+
+// block-wide exclusive prefix of one value per thread (4 waves); `total` = sum over the block
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* wtot /*[4] shared*/, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += o;
+    }
+    __syncthreads();                 // (wtot may still be read from the previous use)
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    total = 0;
+    for (uint32_t w = 0; w < 4; ++w) { if (w < wave) before += wtot[w]; total += wtot[w]; }
+    return before + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mark_kernel: one block per query simprint of the batch.
+//   matches   = the prefix of the list with hamming <= h_max (the list ascends by (hamming, key)): the reference's threshold
+//               on score = 1 - d / ndim (usearch_core.py:182-184), restated on the integer by the host
+//   best      = first occurrence of an asset (key_hi) among the matches = the chunk the reference keeps for (asset, query)
+//               (:191-196: the first one seen wins, a later one only with a strictly better score -- never in an ascending list)
+//   freq_q    = document frequency of the query simprint itself: distinct assets among the first dup_limit rows EQUAL to it
+//               = among the hamming-0 prefix of its list (ascending key, so an asset's rows are adjacent).  Undecidable only when
+//               the whole list of k rows is at distance 0 and k < dup_limit: flagged, the host asks isccsearch_doc_freq.
+// dynamic LDS: keys[S] u64 | idx[S] u32, S = 2^log2s >= 2 k
+// ---------------------------------------------------------------------------------------------
+struct MarkParams {
+    const isccsearch_record* rec;   // batch base
+    const uint32_t* cnt;
+    uint8_t* best;                  // batch base
+    uint32_t* nbest;                // batch base
+    uint32_t* freq_q;               // batch base
+    uint32_t* unknown;              // batch base
+    uint32_t* info;
+    uint32_t k;
+    int h_max;
+    uint32_t dup_limit, log2s;
+};
+__device__ __forceinline__ uint32_t slot_of(uint64_t a, uint32_t log2s) { return (uint32_t)((a * 0x9E3779B97F4A7C15ULL) >> (64 - log2s)); }
+
+__global__ __launch_bounds__(BLOCK) void mark_kernel(const MarkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_nm, s_n0, s_ones, s_best, s_dist;
+    const uint32_t S = 1u << p.log2s, mask = S - 1;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    uint32_t* idx = reinterpret_cast<uint32_t*>(smem + (size_t)S * 8);
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t c = p.cnt[q];
+    const uint32_t n = c == COUNT_OVERFLOW ? 0 : (c < p.k ? c : p.k);
+    const isccsearch_record* r = p.rec + (uint64_t)q * p.k;
+    uint8_t* best = p.best + (uint64_t)q * p.k;
+    for (uint32_t i = tid; i < S; i += BLOCK) { keys[i] = EMPTY; idx[i] = 0xFFFFFFFFu; }
+    if (tid == 0) { s_nm = 0; s_n0 = 0; s_ones = 0xFFFFFFFFu; s_best = 0; s_dist = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += BLOCK) {
+        const int h = r[i].hamming;
+        const int hn = i + 1 < n ? (int)r[i + 1].hamming : 0x10000;
+        if (h <= p.h_max && hn > p.h_max) s_nm = i + 1;
+        if (h == 0 && hn != 0) s_n0 = i + 1;
+    }
+    __syncthreads();
+    const uint32_t nm = s_nm, n0 = s_n0;
+    for (uint32_t i = tid; i < nm; i += BLOCK) {
+        const uint64_t a = r[i].key_hi;
+        if (a == EMPTY) { atomicMin(&s_ones, i); continue; }
+        uint32_t s = slot_of(a, p.log2s);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY, (unsigned long long)a);
+            if (old == EMPTY || old == a) { atomicMin(&idx[s], i); break; }
+            s = (s + 1) & mask;
+        }
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < p.k; i += BLOCK) {
+        uint8_t b = 0;
+        if (i < nm) {
+            const uint64_t a = r[i].key_hi;
+            if (a == EMPTY) b = s_ones == i;
+            else {
+                uint32_t s = slot_of(a, p.log2s);
+                while (keys[s] != a) s = (s + 1) & mask;
+                b = idx[s] == i;
+            }
+        }
+        best[i] = b;
+        mine += b;
+    }
+    // the query's own document frequency
+    const uint32_t m0 = p.dup_limit ? (n0 < p.dup_limit ? n0 : p.dup_limit) : 0;
+    uint32_t dist = 0;
+    for (uint32_t i = tid; i < m0; i += BLOCK) dist += (i == 0 || r[i].key_hi != r[i - 1].key_hi) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) { mine += __shfl_down(mine, off); dist += __shfl_down(dist, off); }
+    if ((tid & 63) == 0) { if (mine) atomicAdd(&s_best, mine); if (dist) atomicAdd(&s_dist, dist); }
+    __syncthreads();
+    if (tid == 0) {
+        p.nbest[q] = s_best;
+        p.freq_q[q] = p.dup_limit ? s_dist : 1u;
+        const uint32_t unk = (p.dup_limit && n0 == n && n == p.k && p.k < p.dup_limit) ? 1u : 0u;
+        p.unknown[q] = unk;
+        if (unk) atomicOr(&p.info[1], 1u);
+    }
+}
+
+// offs[q] = base + exclusive prefix of nbest over the batch (m <= 1 024: four queries per thread); info[0] = base + total
+__global__ __launch_bounds__(BLOCK) void offsets_kernel(const uint32_t* nbest, uint32_t* offs, uint32_t m, uint32_t base, uint32_t* info) {
+    __shared__ uint32_t wtot[4];
+    const uint32_t tid = threadIdx.x;
+    uint32_t running = base;
+    for (uint32_t c0 = 0; c0 < m; c0 += 4 * BLOCK) {
+        uint32_t v[4], sum = 0;
+        for (uint32_t j = 0; j < 4; ++j) { const uint32_t q = c0 + 4 * tid + j; v[j] = q < m ? nbest[q] : 0; sum += v[j]; }
+        uint32_t total;
+        uint32_t at = running + block_exclusive(sum, wtot, total);
+        for (uint32_t j = 0; j < 4; ++j) { const uint32_t q = c0 + 4 * tid + j; if (q < m) offs[q] = at; at += v[j]; }
+        running += total;
+    }
+    if (tid == 0) info[0] = running;
+}
+
+// the best entries of query q, in rank order, to positions offs[q] ...
+struct CompactParams {
+    const isccsearch_record* rec;   // batch base
+    const uint8_t* best;            // batch base
+    const uint32_t* offs;           // batch base
+    uint64_t* c_asset;
+    uint32_t* c_entry;
+    uint32_t k, pos;
+};
+__global__ __launch_bounds__(BLOCK) void compact_kernel(const CompactParams p) {
+    __shared__ uint32_t wtot[4];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const isccsearch_record* r = p.rec + (uint64_t)q * p.k;
+    const uint8_t* best = p.best + (uint64_t)q * p.k;
+    uint32_t running = p.offs[q];
+    for (uint32_t c0 = 0; c0 < p.k; c0 += BLOCK) {
+        const uint32_t i = c0 + tid;
+        const uint32_t f = i < p.k ? best[i] : 0;
+        uint32_t total;
+        const uint32_t at = running + block_exclusive(f, wtot, total);
+        if (f) { p.c_asset[at] = r[i].key_hi; p.c_entry[at] = (p.pos + q) * p.k + i; }
+        running += total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// score_kernel: one thread per sorted entry; the thread at the head of an asset's run scores the asset.
+//   usearch_core.py:215-236 -- total_idf and weighted_sim over the matched query simprints in ascending query order (the
+//   insertion order of best_per_query), then total_idf over every unmatched query simprint in ascending order; score =
+//   weighted / total when total > 0.  Sequential float64 operations with IEEE rounding, none contracted.
+// ---------------------------------------------------------------------------------------------
+struct ScoreParams {
+    const uint64_t* asset;          // sorted
+    const uint32_t* entry;          // sorted along
+    const isccsearch_record* rec;
+    const uint32_t* rows;
+    const uint32_t* freq_col;
+    const uint32_t* freq_q;
+    const double* sim_tab;
+    const double* idf_tab;
+    double* score;
+    uint32_t* order;
+    uint32_t* matches;
+    uint32_t* n_assets;
+    uint32_t entries, nq, k, dup_limit;
+};
+__global__ __launch_bounds__(BLOCK) void score_kernel(const ScoreParams p) {
+    // HIP's __dadd_rn / __dmul_rn are plain `+` / `*`, and device code is compiled with -ffp-contract=fast: without this pragma
+    // (and the file's -ffp-contract=off) `weighted + idf * sim` becomes ONE fused multiply-add -- a single rounding where the
+    // reference's Python does two (found by tests/test_gpu_simprint_score.py: scores one ulp off)
+#pragma clang fp contract(off)
+    const uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+    bool head = false;
+    if (e < p.entries) {
+        const uint64_t a = p.asset[e];
+        head = e == 0 || p.asset[e - 1] != a;
+        p.order[e] = e;
+        if (!head) { p.score[e] = -1.0; p.matches[e] = 0; }
+        else {
+            double total = 0.0, weighted = 0.0;
+            uint32_t j = e;
+            while (j < p.entries && p.asset[j] == a) {
+                const uint32_t ent = p.entry[j];
+                uint32_t f = 0;
+                if (p.dup_limit) { f = p.freq_col[p.rows[ent]]; f = f < p.dup_limit ? f : p.dup_limit; }
+                const double idf = p.idf_tab[f];
+                total = total + idf;
+                const double product = idf * p.sim_tab[p.rec[ent].hamming];
+                weighted = weighted + product;
+                ++j;
+            }
+            const uint32_t end = j;
+            j = e;
+            uint32_t next_q = p.entry[e] / p.k;
+            for (uint32_t qi = 0; qi < p.nq; ++qi) {
+                if (qi == next_q) { ++j; next_q = j < end ? p.entry[j] / p.k : 0xFFFFFFFFu; continue; }
+                uint32_t f = 0;
+                if (p.dup_limit) { f = p.freq_q[qi]; f = f < p.dup_limit ? f : p.dup_limit; }
+                total = total + p.idf_tab[f];
+            }
+            p.score[e] = total > 0.0 ? weighted / total : 0.0;       // (f64 division: correctly rounded by default)
+            p.matches[e] = end - e;
+        }
+    }
+    const unsigned long long heads = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && heads) atomicAdd(p.n_assets, (uint32_t)__popcll(heads));
+}
+
+// ---------------------------------------------------------------------------------------------
+// emit_kernel (one block): the first min(limit, assets) runs in (-score, asset) order -> pinned host memory
+// ---------------------------------------------------------------------------------------------
+struct EmitParams {
+    const double* score;            // sorted descending
+    const uint32_t* order;          // run head of every sorted position
+    const uint64_t* asset;
+    const uint32_t* entry;
+    const uint32_t* matches;
+    const uint32_t* n_assets;
+    const isccsearch_record* rec;
+    const uint32_t* rows;
+    const uint32_t* freq_col;
+    const uint64_t* col[4];
+    uint32_t* first;                // device scratch [limit]
+    isccsearch_simprint_result* out_results;
+    isccsearch_simprint_chunk* out_chunks;
+    uint64_t* out_chunk_words;
+    uint32_t* out_info;
+    uint32_t limit, k, W, dup_limit;
+};
+__global__ __launch_bounds__(BLOCK) void emit_kernel(const EmitParams p) {
+    __shared__ uint32_t wtot[4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t assets = *p.n_assets;
+    const uint32_t n = assets < p.limit ? assets : p.limit;
+    uint32_t running = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += BLOCK) {
+        const uint32_t r = c0 + tid;
+        const uint32_t e = r < n ? p.order[r] : 0;
+        const uint32_t m = r < n ? p.matches[e] : 0;
+        uint32_t total;
+        const uint32_t at = running + block_exclusive(m, wtot, total);
+        if (r < n) {
+            isccsearch_simprint_result res;
+            res.asset = p.asset[e];
+            res.score = p.score[r];
+            res.matches = m;
+            res.first_chunk = at;
+            p.out_results[r] = res;
+            p.first[r] = at;
+        }
+        running += total;
+    }
+    if (tid == 0) { p.out_info[0] = n; p.out_info[1] = assets; p.out_info[2] = 0; p.out_info[3] = p.out_chunks ? running : 0; }
+    if (!p.out_chunks) return;
+    __syncthreads();                 // p.first written by this block
+    for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t e = p.order[r], m = p.matches[e], at = p.first[r];
+        for (uint32_t j = tid; j < m; j += BLOCK) {
+            const uint32_t ent = p.entry[e + j];
+            const isccsearch_record& rec = p.rec[ent];
+            const uint32_t row = p.rows[ent];
+            isccsearch_simprint_chunk c;
+            c.key_lo = rec.key_lo;
+            c.query = ent / p.k;
+            c.hamming = rec.hamming;
+            c.freq = p.dup_limit ? p.freq_col[row] : 1u;
+            c.reserved = 0;
+            p.out_chunks[at + j] = c;
+            if (p.out_chunk_words)
+                for (uint32_t w = 0; w < p.W; ++w) p.out_chunk_words[(uint64_t)(at + j) * p.W + w] = p.col[w][row];
+        }
+    }
+}
+
+uint32_t log2_slots(uint32_t k) {   // hash slots of mark_kernel: the power of two >= 2 k (>= 64)
+    uint32_t l = 6;
+    while ((1u << l) < 2 * k) ++l;
+    return l;
+}
+
+}  // namespace
+
+size_t sort_temp_bytes(size_t entries) {
+    size_t a = 0, b = 0;
+    uint64_t* k64 = nullptr;
+    double* kd = nullptr;
+    uint32_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, a, k64, k64, v, v, entries, 0, 64, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs_desc(nullptr, b, kd, kd, v, v, entries, 0, 64, (hipStream_t) nullptr);
+    return a > b ? a : b;
+}
+
+hipError_t queue_batch(const Buffers& b, const BatchArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        // k = 4 096: 8 192 slots x 12 bytes
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mark_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipError_t e = hipMemsetAsync(a.info, 0, INFO_WORDS * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const size_t off = (size_t)a.pos * a.k;
+    MarkParams mp{b.rec + off, a.cnt, b.best + off, b.nbest + a.pos, b.freq_q + a.pos, b.unknown + a.pos, a.info, a.k, a.h_max, a.dup_limit, log2_slots(a.k)};
+    const size_t lds = ((size_t)1 << mp.log2s) * 12;
+    hipLaunchKernelGGL(mark_kernel, dim3(a.m), dim3(BLOCK), lds, stream, mp);
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(BLOCK), 0, stream, b.nbest + a.pos, b.offs + a.pos, a.m, a.base, a.info);
+    CompactParams cp{b.rec + off, b.best + off, b.offs + a.pos, b.c_asset[0], b.c_entry[0], a.k, a.pos};
+    hipLaunchKernelGGL(compact_kernel, dim3(a.m), dim3(BLOCK), 0, stream, cp);
+    return hipGetLastError();
+}
+
+hipError_t queue_score(Buffers& b, const ScoreArgs& a, hipStream_t stream) {
+    hipError_t e;
+    size_t bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.c_asset[0], b.c_asset[1], b.c_entry[0], b.c_entry[1], a.entries, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(b.n_assets, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    ScoreParams sp{b.c_asset[1], b.c_entry[1], b.rec, b.rows, a.freq_col, b.freq_q, a.sim_tab, a.idf_tab,
+                   b.score[0], b.order[0], b.matches, b.n_assets, a.entries, a.nq, a.k, a.dup_limit};
+    hipLaunchKernelGGL(score_kernel, dim3((a.entries + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, sp);
+    bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs_desc(b.temp, bytes, b.score[0], b.score[1], b.order[0], b.order[1], a.entries, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    EmitParams ep{};
+    ep.score = b.score[1]; ep.order = b.order[1]; ep.asset = b.c_asset[1]; ep.entry = b.c_entry[1]; ep.matches = b.matches;
+    ep.n_assets = b.n_assets; ep.rec = b.rec; ep.rows = b.rows; ep.freq_col = a.freq_col;
+    for (uint32_t w = 0; w < 4; ++w) ep.col[w] = a.col[w];
+    ep.first = b.order[0];           // the descending sort has consumed its input
+    ep.out_results = a.out_results; ep.out_chunks = a.out_chunks; ep.out_chunk_words = a.out_chunk_words; ep.out_info = a.out_info;
+    ep.limit = a.limit; ep.k = a.k; ep.W = a.W; ep.dup_limit = a.dup_limit;
+    hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(BLOCK), 0, stream, ep);
+    return hipGetLastError();
+}
+
+}  // namespace isksp

@@ -367,6 +367,33 @@ class HipTable:
                 self.engine.handle, self.id, n, _lib.ptr(keys, ctypes.c_uint64), int(dup_limit), _lib.ptr(out, ctypes.c_uint32)))
         return out
 
+    def simprint_score(self, q_words, count, max_hamming, threshold, limit, total_assets, dup_limit, detailed):
+        # type: (np.ndarray, int, int | None, float, int, int, int, bool) -> tuple
+        """
+        Neighbour search + asset scoring in one call, the lists never leaving the device (``isccsearch_simprint_score``:
+        ``usearch_core.py:137-269``).  Returns (results [n] ``SIMPRINT_RESULT_DTYPE``, chunks [c] ``SIMPRINT_CHUNK_DTYPE`` or
+        None, chunk words uint64 [c, max_words] or None, info = (results, assets matched, longest neighbour list, chunks)).
+        """
+        q_words = self._words(q_words)
+        nq = q_words.shape[0]
+        if count < 1:
+            raise ValueError("`count` must be >= 1")
+        limit = int(limit)
+        results = np.empty(limit, dtype=_lib.SIMPRINT_RESULT_DTYPE)
+        info = np.zeros(4, dtype=np.uint32)
+        chunks = words = None
+        if detailed:
+            cap = min(limit * nq, nq * int(count))
+            chunks = np.empty(cap, dtype=_lib.SIMPRINT_CHUNK_DTYPE)
+            words = np.empty((cap, self.max_words), dtype=np.uint64)
+        if nq:
+            _lib.check(self.engine._lib.isccsearch_simprint_score(
+                self.engine.handle, self.id, nq, _lib.ptr(q_words), int(count), -1 if max_hamming is None else int(max_hamming),
+                float(threshold), limit, int(total_assets), int(dup_limit),
+                _lib.ptr(results), _lib.ptr(chunks), _lib.ptr(words), _lib.ptr(info)))
+        n, c = int(info[0]), int(info[3])
+        return results[:n], (chunks[:c] if detailed else None), (words[:c] if detailed else None), tuple(int(x) for x in info)
+
     def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr, max_hamming=None, consumer_stream=None, hint=None):
         # type: (np.ndarray, np.ndarray | None, int, int, int, int | None, int | None, int | None) -> None
         """

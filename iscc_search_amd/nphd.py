@@ -390,6 +390,18 @@ class HipIndex128:
             out.append(Matches(words_to_key128(keys[q, :c]), ham[q, :c].astype(np.float32), ham[q, :c].copy(), pbits[q, :c].copy()))
         return out[0] if single else BatchMatches(out)
 
+    @property
+    def scores_on_device(self):
+        # type: () -> bool
+        """Whether the table behind this index scores simprint matches itself (``isccsearch_simprint_score``; a sharded table does not)."""
+        return hasattr(self._table, "simprint_score")
+
+    def score_assets(self, vectors, count, max_hamming, threshold, limit, total_assets, dup_limit, detailed):
+        # type: (np.ndarray, int, int | None, float, int, int, int, bool) -> tuple
+        """``HipTable.simprint_score`` for byte vectors: search + scoring of ``usearch_core.py:137-269`` in one device round trip."""
+        q_words, _ = pack_bytes(self._vectors(vectors), self._table.max_words)
+        return self._table.simprint_score(q_words, count, max_hamming, threshold, limit, total_assets, dup_limit, detailed)
+
     def get_freq(self, keys, dup_limit=1000):
         # type: (list[bytes], int) -> np.ndarray
         """Document frequency of the vector stored under each key (0 for absent keys), from the frequency column."""

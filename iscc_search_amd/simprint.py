@@ -20,6 +20,8 @@ from iscc_search_amd._lib import MAX_K
 from iscc_search_amd.nphd import HipIndex128, words_to_key128
 
 CHUNK_POINTER_BYTES = 16
+DOC_FREQ_DUP_LIMIT = 1000   # duplicates looked at per simprint when counting its assets: the reference's safety cap
+                            # (count_doc_freq(dup_limit=1000), lmdb_ops.py:139-166); HipIndex128.get_freq / doc_freq share it
 MAX_OFFSET = 2**32 - 1
 MAX_SIZE = 2**32 - 1
 
@@ -150,6 +152,63 @@ class HipSimprintIndex:
         """
         if not simprints or len(self._index) == 0:
             return []
+        if (device_doc_freq or doc_freq_fn is None) and self._index.scores_on_device:
+            return self._search_raw_device(simprints, limit, threshold, detailed, total_assets, DOC_FREQ_DUP_LIMIT if device_doc_freq else 0)
+        return self._search_raw_host(simprints, limit, threshold, detailed, doc_freq_fn, total_assets, device_doc_freq)
+
+    def _radius_for(self, threshold):
+        # type: (float) -> int
+        """Largest distance whose score ``1 - d / ndim`` still passes ``threshold`` (0 when none does)."""
+        radius = self.ndim
+        while radius > 0 and 1.0 - radius / self.ndim < threshold:
+            radius -= 1
+        return radius
+
+    def _search_raw_device(self, simprints, limit, threshold, detailed, total_assets, dup_limit):
+        # type: (list[bytes], int, float, bool, int, int) -> list[SimprintMatchRaw]
+        """
+        The whole of ``usearch_core.py:137-269`` in ONE library call (``isccsearch_simprint_score``): the neighbour lists stay in
+        device memory, the kernels of ``csrc/simprint_score.hip`` apply the threshold, keep the best chunk per (asset, query),
+        sum the IDF weights in the reference's order of float64 additions, sort by (-score, asset) and cut to ``limit``;
+        only those assets (and their matched chunks) come back.  ``dup_limit`` 0: every document frequency is 1
+        (``doc_freq_fn=None``); otherwise the device's own frequencies (``device_doc_freq``).
+        """
+        queries = _pack_simprints(simprints)
+        count = max(1, limit * self.oversampling_factor)
+        radius = None
+        if count > MAX_K:
+            # (see _search_raw_host: beyond the cap the request becomes "every row within the match threshold")
+            radius, count = self._radius_for(threshold), MAX_K
+        results, chunks, words, info = self._index.score_assets(queries, count, radius, threshold, limit, total_assets, dup_limit, detailed)
+        if radius is not None and info[2] >= MAX_K:
+            raise ValueError(
+                f"limit {limit} x oversampling {self.oversampling_factor} = {limit * self.oversampling_factor} neighbours per simprint exceeds the "
+                f"{MAX_K} this backend returns, and a query simprint has that many stored chunks within the match threshold"
+            )
+        out = []
+        nbytes = self.ndim // 8
+        raw_words = np.ascontiguousarray(words).astype(">u8").tobytes() if detailed else b""
+        stride = (nbytes + 7) // 8 * 8
+        for r in results.tolist():
+            asset, score, matches, first = r
+            detail = None
+            if detailed:
+                detail = []
+                for j, (key_lo, qi, ham, freq, _) in enumerate(chunks[first : first + matches].tolist(), start=first):
+                    detail.append(MatchedChunkRaw(
+                        query=simprints[qi], match=raw_words[j * stride : j * stride + nbytes], score=1.0 - ham / self.ndim,
+                        offset=key_lo >> 32, size=key_lo & 0xFFFFFFFF, freq=freq,
+                    ))
+            out.append(SimprintMatchRaw(iscc_id_body=asset.to_bytes(8, "big"), score=score, queried=len(simprints), matches=matches, chunks=detail))
+        return out
+
+    def _search_raw_host(self, simprints, limit, threshold, detailed, doc_freq_fn, total_assets, device_doc_freq):
+        # type: (list[bytes], int, float, bool, Callable[[bytes], int] | None, int, bool) -> list[SimprintMatchRaw]
+        """
+        The same pipeline with the scoring on the host: what a Python ``doc_freq_fn`` callback needs (it cannot run on the
+        device) and what a table sharded over several GPUs uses (the stored simprints and their frequencies live on the
+        owning ranks).  The neighbour search is the device's either way.
+        """
         queries = _pack_simprints(simprints)
         count = max(1, limit * self.oversampling_factor)
         if count <= MAX_K:
@@ -158,9 +217,7 @@ class HipSimprintIndex:
             # The reference asks usearch for `count` neighbours unbounded (usearch_core.py:164); the engine returns at most
             # MAX_K per query.  Only neighbours scoring >= threshold survive the filter below, i.e. rows within a fixed
             # radius: list exactly those.  A list that still fills the cap cannot be represented -- refuse, never truncate.
-            radius = self.ndim
-            while radius > 0 and 1.0 - radius / self.ndim < threshold:
-                radius -= 1
+            radius = self._radius_for(threshold)
             key_words, ham, cnt = self._index.search_arrays(queries, count=MAX_K, max_hamming=radius)
             if int(cnt.max(initial=0)) >= MAX_K and count > MAX_K:
                 raise ValueError(

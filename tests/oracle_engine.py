@@ -139,6 +139,48 @@ class OracleTable:
             out[i] = self.doc_freq(words[i : i + 1], nb[i : i + 1], dup_limit)[0]
         return out
 
+    def simprint_score(self, q_words, count, max_hamming, threshold, limit, total_assets, dup_limit, detailed):
+        """``HipTable.simprint_score`` answered by the oracle's neighbours and the plain-loop checker (``tests/simprint_checker.py``)."""
+        from iscc_search_amd._lib import SIMPRINT_CHUNK_DTYPE, SIMPRINT_RESULT_DTYPE
+        from simprint_checker import score_lists
+
+        q_words = np.asarray(q_words, dtype=np.uint64).reshape(-1, self.max_words)
+        nq = q_words.shape[0]
+        if max_hamming is None:
+            keys, ham, _, cnt = self.search(q_words, None, count)
+        else:
+            keys, ham, _, cnt = self.search_within(q_words, None, count, max_hamming)
+        to_bytes = lambda w, n: np.ascontiguousarray(w, dtype=np.uint64).astype(">u8").tobytes()[:n]
+        lists = [[(to_bytes(keys[q, i], 16), int(ham[q, i])) for i in range(int(cnt[q]))] for q in range(nq)]
+        simprints = [to_bytes(q_words[q], self.max_bytes) for q in range(nq)]
+
+        def stored(key):
+            words, nb = self.get(np.frombuffer(key, dtype=">u8").astype(np.uint64).reshape(1, 2))
+            return to_bytes(words[0], self.max_bytes) if nb[0] else None
+
+        def freq(sp_bytes):
+            buf = np.zeros(self.max_words * 8, dtype=np.uint8)
+            buf[: len(sp_bytes)] = np.frombuffer(sp_bytes, dtype=np.uint8)
+            return int(self.doc_freq(buf.view(">u8").astype(np.uint64).reshape(1, -1), None, dup_limit)[0])
+
+        scored = score_lists(simprints, lists, 8 * self.max_bytes, limit, threshold, stored, freq if dup_limit else None, total_assets)
+        results = np.zeros(len(scored), dtype=SIMPRINT_RESULT_DTYPE)
+        chunk_rows, word_rows = [], []
+        for r, (asset, score, matches, chunks) in enumerate(scored):
+            results[r] = (int.from_bytes(asset, "big"), score, matches, len(chunk_rows))
+            for qi, match, sim, offset, size, f in chunks:
+                h = [int(d) for (_, d) in lists[qi] if 1.0 - (float(d) / (8 * self.max_bytes)) == sim][0]
+                chunk_rows.append(((offset << 32) | size, qi, h, f, 0))
+                buf = np.zeros(self.max_words * 8, dtype=np.uint8)
+                buf[: len(match)] = np.frombuffer(match, dtype=np.uint8)
+                word_rows.append(buf.view(">u8").astype(np.uint64))
+        info = (len(scored), 0, int(cnt.max(initial=0)), len(chunk_rows))
+        if not detailed:
+            return results, None, None, info
+        chunks = np.array(chunk_rows, dtype=SIMPRINT_CHUNK_DTYPE) if chunk_rows else np.zeros(0, dtype=SIMPRINT_CHUNK_DTYPE)
+        words = np.stack(word_rows) if word_rows else np.zeros((0, self.max_words), dtype=np.uint64)
+        return results, chunks, words, info
+
     def search_records(self, q_words, q_nbytes, k, max_hamming=None):
         """Structured records [nq, k] + counts, as the device exchange format."""
         if max_hamming is None:
