@@ -241,10 +241,11 @@ int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const 
  *                   collisions (isccsearch_doc_freq) -- what the reference's doc_freq_fn computes with an LMDB cursor walk
  *                   (usearch/index.py:1395-1403, lmdb_ops.py:139-166)
  *   dup_limit == 0  every frequency is 1 (the reference's doc_freq_fn = None, :204-211)
- * 128-bit-key Hamming tables only.  out_results[limit]; out_chunks[limit * nq] and out_chunk_words[limit * nq * max_words]
+ * 128-bit-key Hamming tables only, nq <= ISCCSEARCH_MAX_SCORED_SIMPRINTS.  out_results[limit]; out_chunks[limit * nq] and out_chunk_words[limit * nq * max_words]
  * (both or neither; chunks of result r are out_chunks[first_chunk .. first_chunk + matches), ascending query index, words =
  * the STORED simprint); out_info[4] = {results written, assets matched, longest neighbour list (what a caller that asked for
  * a radius compares with `count` to see a list that filled the cap), chunks written}. */
+#define ISCCSEARCH_MAX_SCORED_SIMPRINTS 8192
 typedef struct isccsearch_simprint_result {
     uint64_t asset;        /* first key word: ISCC-ID body */
     double   score;

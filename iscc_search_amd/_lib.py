@@ -20,6 +20,7 @@ MAX_BYTES = 32
 MAX_K = 4096
 COUNT_OVERFLOW = 0xFFFFFFFF   # ISCCSEARCH_COUNT_OVERFLOW: a count the asynchronous device search could not complete
 ADD_TRUSTED_UNIQUE = 1
+MAX_SCORED_SIMPRINTS = 8192   # ISCCSEARCH_MAX_SCORED_SIMPRINTS: query simprints one isccsearch_simprint_score call takes
 
 # every symbol include/isccsearch.h declares
 EXPORTS = (

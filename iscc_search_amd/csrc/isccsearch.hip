@@ -249,7 +249,7 @@ struct isccsearch_handle {
     DevBuf<uint32_t> d_sp_rows, d_sp_nbest, d_sp_offs, d_sp_freqq, d_sp_unknown, d_sp_entry[2], d_sp_order[2], d_sp_matches, d_sp_nassets;
     DevBuf<unsigned char> d_sp_best, d_sp_temp;
     DevBuf<uint64_t> d_sp_asset[2];
-    DevBuf<double> d_sp_score[2], d_sp_tab;
+    DevBuf<double> d_sp_score[2], d_sp_tab, d_sp_ws, d_sp_idfq;
     PinBuf<double> p_sp_tab;
     PinBuf<unsigned char> p_sp_out;
     // the similarity / IDF tables on the device are those of (bits, total_assets, dup_limit):
@@ -1166,7 +1166,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         h->d_sp_rec.release(); h->d_sp_rows.release(); h->d_sp_nbest.release(); h->d_sp_offs.release(); h->d_sp_freqq.release();
         h->d_sp_unknown.release(); h->d_sp_matches.release(); h->d_sp_nassets.release(); h->d_sp_best.release(); h->d_sp_temp.release();
         for (int i = 0; i < 2; ++i) { h->d_sp_entry[i].release(); h->d_sp_order[i].release(); h->d_sp_asset[i].release(); h->d_sp_score[i].release(); }
-        h->d_sp_tab.release(); h->p_sp_tab.release(); h->p_sp_out.release();
+        h->d_sp_tab.release(); h->p_sp_tab.release(); h->p_sp_out.release(); h->d_sp_ws.release(); h->d_sp_idfq.release();
         if (h->d_rank) (void)hipFree(h->d_rank);
         for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         for (hipEvent_t e : {h->ev_done, h->ev_staged, h->ev_producer}) if (e) (void)hipEventDestroy(e);
@@ -1663,6 +1663,7 @@ int isccsearch_get_freq(isccsearch_handle* h, uint32_t table, uint64_t n, const 
     return 0;
 }
 
+static_assert(isksp::MAX_QUERY_SIMPRINTS == ISCCSEARCH_MAX_SCORED_SIMPRINTS, "header and kernels disagree");
 // isccsearch_simprint_score: where a search leaves its lists for the scoring kernels instead of handing them to the host
 struct ScoreSink {
     isksp::Buffers buf{};
@@ -2252,7 +2253,7 @@ int isccsearch_simprint_score(isccsearch_handle* h, uint32_t table, uint32_t nq,
     out_info[0] = out_info[1] = out_info[2] = out_info[3] = 0;
     if (nq == 0) return 0;
     if (!q_words || !out_results || (out_chunks == nullptr) != (out_chunk_words == nullptr)) return fail(-EINVAL, "NULL argument");
-    if ((uint64_t)nq * count > 0xFFFFFFFFull) return fail(-E2BIG, "%u query simprints x %u neighbours exceed 2^32 entries", nq, count);
+    if (nq > isksp::MAX_QUERY_SIMPRINTS) return fail(-E2BIG, "%u query simprints exceed the %u one scoring call takes", nq, isksp::MAX_QUERY_SIMPRINTS);
     if (!(threshold == threshold)) return fail(-EINVAL, "threshold is not a number");
     std::lock_guard<std::mutex> lk(h->mu);
     Table* tp;
@@ -2315,7 +2316,7 @@ int isccsearch_simprint_score(isccsearch_handle* h, uint32_t table, uint32_t nq,
             b.c_asset[i] = h->d_sp_asset[i].p; b.c_entry[i] = h->d_sp_entry[i].p;
             b.score[i] = h->d_sp_score[i].p; b.order[i] = h->d_sp_order[i].p;
         }
-        b.matches = h->d_sp_matches.p;
+        b.matches = h->d_sp_matches.p; b.ws = h->d_sp_ws.p; b.idf_q = h->d_sp_idfq.p;
         b.temp = h->d_sp_temp.p; b.temp_bytes = h->d_sp_temp.n;
     };
     bind();
@@ -2344,6 +2345,8 @@ int isccsearch_simprint_score(isccsearch_handle* h, uint32_t table, uint32_t nq,
         if ((rc = h->d_sp_order[i].ensure(entries))) return rc;
     }
     if ((rc = h->d_sp_matches.ensure(entries))) return rc;
+    if ((rc = h->d_sp_ws.ensure(entries))) return rc;
+    if ((rc = h->d_sp_idfq.ensure(nq))) return rc;
     if ((rc = h->d_sp_temp.ensure(isksp::sort_temp_bytes(entries)))) return rc;
     bind();
     // outputs in pinned memory, written by the emit kernel itself: {info[4] | results[limit] | chunks | chunk words}

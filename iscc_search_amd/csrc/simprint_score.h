@@ -29,6 +29,7 @@
 
 namespace isksp {
 
+constexpr uint32_t MAX_QUERY_SIMPRINTS = 8192;   // score_kernel keeps one bit per query simprint and thread in LDS (64 threads x 1 KB)
 constexpr uint32_t INFO_WORDS = 4;   // per batch, behind counts / flags / k-th distances: {entries appended so far, some query's
                                      // document frequency could not be read off its list, -, -}
 
@@ -46,6 +47,8 @@ struct Buffers {
     double* score[2];               // [entries] per sorted entry: the asset's score at its run head, -1 elsewhere
     uint32_t* order[2];             // [entries] sort payload: index of the run head
     uint32_t* matches;              // [entries] matched query simprints of the run starting here
+    double* ws;                     // [entries] IDF weight x similarity of every sorted entry
+    double* idf_q;                  // [nq] IDF of every query simprint's own document frequency
     uint32_t* n_assets;             // [1]
     void* temp;                     // rocPRIM scratch
     size_t temp_bytes;

@@ -116,24 +116,27 @@ __global__ __launch_bounds__(BLOCK) void mark_kernel(const MarkParams p) {
         p.freq_q[q] = p.dup_limit ? s_dist : 1u;
         const uint32_t unk = (p.dup_limit && n0 == n && n == p.k && p.k < p.dup_limit) ? 1u : 0u;
         p.unknown[q] = unk;
-        if (unk) atomicOr(&p.info[1], 1u);
     }
 }
 
-// offs[q] = base + exclusive prefix of nbest over the batch (m <= 1 024: four queries per thread); info[0] = base + total
-__global__ __launch_bounds__(BLOCK) void offsets_kernel(const uint32_t* nbest, uint32_t* offs, uint32_t m, uint32_t base, uint32_t* info) {
-    __shared__ uint32_t wtot[4];
+// offs[q] = base + exclusive prefix of nbest over the batch (m <= 1 024: four queries per thread); info = {base + total, some
+// query's frequency is unknown, 0, 0}
+__global__ __launch_bounds__(BLOCK) void offsets_kernel(const uint32_t* nbest, const uint32_t* unknown, uint32_t* offs, uint32_t m, uint32_t base, uint32_t* info) {
+    __shared__ uint32_t wtot[4], wunk[4];
     const uint32_t tid = threadIdx.x;
-    uint32_t running = base;
+    uint32_t running = base, unk = 0;
     for (uint32_t c0 = 0; c0 < m; c0 += 4 * BLOCK) {
         uint32_t v[4], sum = 0;
-        for (uint32_t j = 0; j < 4; ++j) { const uint32_t q = c0 + 4 * tid + j; v[j] = q < m ? nbest[q] : 0; sum += v[j]; }
+        for (uint32_t j = 0; j < 4; ++j) { const uint32_t q = c0 + 4 * tid + j; v[j] = q < m ? nbest[q] : 0; sum += v[j]; unk |= q < m ? unknown[q] : 0; }
         uint32_t total;
         uint32_t at = running + block_exclusive(sum, wtot, total);
         for (uint32_t j = 0; j < 4; ++j) { const uint32_t q = c0 + 4 * tid + j; if (q < m) offs[q] = at; at += v[j]; }
         running += total;
     }
-    if (tid == 0) info[0] = running;
+    const unsigned long long any = __ballot(unk != 0);
+    if ((tid & 63) == 0) wunk[tid >> 6] = any != 0;
+    __syncthreads();
+    if (tid == 0) { info[0] = running; info[1] = wunk[0] | wunk[1] | wunk[2] | wunk[3]; info[2] = 0; info[3] = 0; }
 }
 
 // the best entries of query q, in rank order, to positions offs[q] ...
@@ -162,70 +165,130 @@ __global__ __launch_bounds__(BLOCK) void compact_kernel(const CompactParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// score_kernel: one thread per sorted entry; the thread at the head of an asset's run scores the asset.
-//   usearch_core.py:215-236 -- total_idf and weighted_sim over the matched query simprints in ascending query order (the
-//   insertion order of best_per_query), then total_idf over every unmatched query simprint in ascending order; score =
-//   weighted / total when total > 0.  Sequential float64 operations with IEEE rounding, none contracted.
+// weights_kernel: per sorted entry, its IDF weight and weight x similarity (two roundings, as `idf * sim` then `+=` in
+// usearch_core.py:224-226), and the query index; per query simprint, the IDF of its own document frequency (:232-234).
+// Everything score_kernel's sequential sums need lies in contiguous arrays afterwards: no pointer chasing in the chain.
 // ---------------------------------------------------------------------------------------------
-struct ScoreParams {
-    const uint64_t* asset;          // sorted
-    const uint32_t* entry;          // sorted along
+struct WeightParams {
+    const uint32_t* entry;          // sorted by asset
     const isccsearch_record* rec;
     const uint32_t* rows;
     const uint32_t* freq_col;
     const uint32_t* freq_q;
     const double* sim_tab;
     const double* idf_tab;
+    double* w;                      // [entries]
+    double* ws;                     // [entries]
+    uint32_t* q;                    // [entries]
+    double* idf_q;                  // [nq]
+    uint32_t* n_assets;             // zeroed here for score_kernel
+    uint32_t entries, nq, k, dup_limit;
+};
+__global__ __launch_bounds__(BLOCK) void weights_kernel(const WeightParams p) {
+#pragma clang fp contract(off)
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t == 0) *p.n_assets = 0;
+    if (t < p.entries) {
+        const uint32_t ent = p.entry[t];
+        uint32_t f = 0;
+        if (p.dup_limit) { f = p.freq_col[p.rows[ent]]; f = f < p.dup_limit ? f : p.dup_limit; }
+        const double idf = p.idf_tab[f];
+        p.w[t] = idf;
+        p.ws[t] = idf * p.sim_tab[p.rec[ent].hamming];
+        p.q[t] = ent / p.k;
+    }
+    if (t < p.nq) {
+        uint32_t f = 0;
+        if (p.dup_limit) { f = p.freq_q[t]; f = f < p.dup_limit ? f : p.dup_limit; }
+        p.idf_q[t] = p.idf_tab[f];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// score_kernel: one thread per sorted entry; the thread at the head of an asset's run scores the asset.
+//   usearch_core.py:215-236 -- total_idf and weighted_sim over the matched query simprints in ascending query order (the
+//   insertion order of best_per_query), then total_idf over every unmatched query simprint in ascending order; score =
+//   weighted / total when total > 0.  Sequential float64 operations with IEEE rounding, none contracted.
+//   The run is walked four entries at a time (its loads do not depend on the sums), and leaves a bit per matched query in the
+//   thread's LDS row, so that the second sum runs over the query simprints without touching memory it has to wait for.
+// dynamic LDS: mask[words][threads] u64, words = ceil(nq / 64)
+// ---------------------------------------------------------------------------------------------
+struct ScoreParams {
+    const uint64_t* asset;          // sorted
+    const double* w;
+    const double* ws;
+    const uint32_t* q;
+    const double* idf_q;
     double* score;
     uint32_t* order;
     uint32_t* matches;
     uint32_t* n_assets;
-    uint32_t entries, nq, k, dup_limit;
+    uint32_t entries, nq, words;
 };
-__global__ __launch_bounds__(BLOCK) void score_kernel(const ScoreParams p) {
+__global__ void score_kernel(const ScoreParams p) {
     // HIP's __dadd_rn / __dmul_rn are plain `+` / `*`, and device code is compiled with -ffp-contract=fast: without this pragma
     // (and the file's -ffp-contract=off) `weighted + idf * sim` becomes ONE fused multiply-add -- a single rounding where the
     // reference's Python does two (found by tests/test_gpu_simprint_score.py: scores one ulp off)
 #pragma clang fp contract(off)
-    const uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
-    bool head = false;
-    if (e < p.entries) {
-        const uint64_t a = p.asset[e];
-        head = e == 0 || p.asset[e - 1] != a;
-        p.order[e] = e;
-        if (!head) { p.score[e] = -1.0; p.matches[e] = 0; }
-        else {
-            double total = 0.0, weighted = 0.0;
-            uint32_t j = e;
-            while (j < p.entries && p.asset[j] == a) {
-                const uint32_t ent = p.entry[j];
-                uint32_t f = 0;
-                if (p.dup_limit) { f = p.freq_col[p.rows[ent]]; f = f < p.dup_limit ? f : p.dup_limit; }
-                const double idf = p.idf_tab[f];
-                total = total + idf;
-                const double product = idf * p.sim_tab[p.rec[ent].hamming];
-                weighted = weighted + product;
-                ++j;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(smem);
+    const uint32_t T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t e = blockIdx.x * T + tid;
+    const uint64_t a = e < p.entries ? p.asset[e] : 0;
+    const bool head = e < p.entries && (e == 0 || p.asset[e - 1] != a);
+    double total = 0.0, weighted = 0.0;
+    uint32_t end = e;
+    if (e < p.entries) p.order[e] = e;
+    if (head) {
+        // 1. the matched query simprints, ascending (the run is sorted by asset, stably: by query inside an asset)
+        for (uint32_t w = 0; w < p.words; ++w) mask[w * T + tid] = 0;
+        constexpr int U = 8;
+        uint32_t j = e;
+        for (bool more = true; more;) {
+            uint64_t aa[U]; double ww[U], ss[U]; uint32_t qq[U];
+            for (int u = 0; u < U; ++u) {
+                const uint32_t jj = j + u < p.entries ? j + u : p.entries - 1;
+                aa[u] = p.asset[jj]; ww[u] = p.w[jj]; ss[u] = p.ws[jj]; qq[u] = p.q[jj];
             }
-            const uint32_t end = j;
-            j = e;
-            uint32_t next_q = p.entry[e] / p.k;
-            for (uint32_t qi = 0; qi < p.nq; ++qi) {
-                if (qi == next_q) { ++j; next_q = j < end ? p.entry[j] / p.k : 0xFFFFFFFFu; continue; }
-                uint32_t f = 0;
-                if (p.dup_limit) { f = p.freq_q[qi]; f = f < p.dup_limit ? f : p.dup_limit; }
-                total = total + p.idf_tab[f];
+            int u = 0;
+            for (; u < U; ++u) {
+                if (j + u >= p.entries || aa[u] != a) { more = false; break; }
+                total = total + ww[u];
+                weighted = weighted + ss[u];
+                mask[(qq[u] >> 6) * T + tid] |= 1ull << (qq[u] & 63);
             }
-            p.score[e] = total > 0.0 ? weighted / total : 0.0;       // (f64 division: correctly rounded by default)
-            p.matches[e] = end - e;
+            j += u;
+        }
+        end = j;
+    }
+    // 2. every unmatched query simprint, ascending.  The whole wave walks the queries together -- lane l holds the IDF of query
+    //    64 w + l, each step broadcasts one of them from a register (v_readlane) -- so nothing in a head's chain of additions waits
+    //    for memory; lanes that head no run tag along.
+    if (__ballot(head)) {
+        for (uint32_t w = 0; w < p.words; ++w) {
+            const uint32_t q0 = 64 * w, n = p.nq - q0 < 64 ? p.nq - q0 : 64;
+            // (bits of queries beyond nq are set: skipped like matched ones, so that the loop below has a fixed trip count)
+            const unsigned long long m = (head ? mask[w * T + tid] : ~0ULL) | (n < 64 ? ~0ULL << n : 0ULL);
+            const double mine = lane < n ? p.idf_q[q0 + lane] : 0.0;
+            const int lo = __double2loint(mine), hi = __double2hiint(mine);
+#pragma unroll
+            for (uint32_t i = 0; i < 64; ++i) {
+                const double x = __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
+                total = (m >> i) & 1 ? total : total + x;
+            }
         }
     }
+    if (e < p.entries) {
+        p.score[e] = !head ? -1.0 : (total > 0.0 ? weighted / total : 0.0);       // (f64 division: correctly rounded by default)
+        p.matches[e] = end - e;
+    }
     const unsigned long long heads = __ballot(head);
-    if ((threadIdx.x & 63) == 0 && heads) atomicAdd(p.n_assets, (uint32_t)__popcll(heads));
+    if (lane == 0 && heads) atomicAdd(p.n_assets, (uint32_t)__popcll(heads));
 }
 
 // ---------------------------------------------------------------------------------------------
-// emit_kernel (one block): the first min(limit, assets) runs in (-score, asset) order -> pinned host memory
+// emit_kernel: block r writes result r of the first min(limit, assets) runs in (-score, asset) order -- and its matched
+// chunks -- into pinned host memory; its chunks start behind those of the results before it.
 // ---------------------------------------------------------------------------------------------
 struct EmitParams {
     const double* score;            // sorted descending
@@ -238,7 +301,6 @@ struct EmitParams {
     const uint32_t* rows;
     const uint32_t* freq_col;
     const uint64_t* col[4];
-    uint32_t* first;                // device scratch [limit]
     isccsearch_simprint_result* out_results;
     isccsearch_simprint_chunk* out_chunks;
     uint64_t* out_chunk_words;
@@ -246,47 +308,43 @@ struct EmitParams {
     uint32_t limit, k, W, dup_limit;
 };
 __global__ __launch_bounds__(BLOCK) void emit_kernel(const EmitParams p) {
-    __shared__ uint32_t wtot[4];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_first;
+    const uint32_t tid = threadIdx.x, r = blockIdx.x;
     const uint32_t assets = *p.n_assets;
     const uint32_t n = assets < p.limit ? assets : p.limit;
-    uint32_t running = 0;
-    for (uint32_t c0 = 0; c0 < n; c0 += BLOCK) {
-        const uint32_t r = c0 + tid;
-        const uint32_t e = r < n ? p.order[r] : 0;
-        const uint32_t m = r < n ? p.matches[e] : 0;
-        uint32_t total;
-        const uint32_t at = running + block_exclusive(m, wtot, total);
-        if (r < n) {
-            isccsearch_simprint_result res;
-            res.asset = p.asset[e];
-            res.score = p.score[r];
-            res.matches = m;
-            res.first_chunk = at;
-            p.out_results[r] = res;
-            p.first[r] = at;
-        }
-        running += total;
+    if (r == 0 && tid == 0) { p.out_info[0] = n; p.out_info[1] = assets; p.out_info[2] = 0; if (n == 0) p.out_info[3] = 0; }
+    if (r >= n) return;
+    if (tid == 0) s_first = 0;
+    __syncthreads();
+    // chunks of the results before this one (block n - 1 also adds its own: the total)
+    uint32_t before = 0;
+    for (uint32_t i = tid; i < r; i += BLOCK) before += p.matches[p.order[i]];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if ((tid & 63) == 0 && before) atomicAdd(&s_first, before);
+    __syncthreads();
+    const uint32_t at = s_first, e = p.order[r], m = p.matches[e];
+    if (tid == 0) {
+        isccsearch_simprint_result res;
+        res.asset = p.asset[e];
+        res.score = p.score[r];
+        res.matches = m;
+        res.first_chunk = at;
+        p.out_results[r] = res;
+        if (r == n - 1) p.out_info[3] = p.out_chunks ? at + m : 0;
     }
-    if (tid == 0) { p.out_info[0] = n; p.out_info[1] = assets; p.out_info[2] = 0; p.out_info[3] = p.out_chunks ? running : 0; }
     if (!p.out_chunks) return;
-    __syncthreads();                 // p.first written by this block
-    for (uint32_t r = 0; r < n; ++r) {
-        const uint32_t e = p.order[r], m = p.matches[e], at = p.first[r];
-        for (uint32_t j = tid; j < m; j += BLOCK) {
-            const uint32_t ent = p.entry[e + j];
-            const isccsearch_record& rec = p.rec[ent];
-            const uint32_t row = p.rows[ent];
-            isccsearch_simprint_chunk c;
-            c.key_lo = rec.key_lo;
-            c.query = ent / p.k;
-            c.hamming = rec.hamming;
-            c.freq = p.dup_limit ? p.freq_col[row] : 1u;
-            c.reserved = 0;
-            p.out_chunks[at + j] = c;
-            if (p.out_chunk_words)
-                for (uint32_t w = 0; w < p.W; ++w) p.out_chunk_words[(uint64_t)(at + j) * p.W + w] = p.col[w][row];
-        }
+    for (uint32_t j = tid; j < m; j += BLOCK) {
+        const uint32_t ent = p.entry[e + j];
+        const isccsearch_record& rec = p.rec[ent];
+        const uint32_t row = p.rows[ent];
+        isccsearch_simprint_chunk c;
+        c.key_lo = rec.key_lo;
+        c.query = ent / p.k;
+        c.hamming = rec.hamming;
+        c.freq = p.dup_limit ? p.freq_col[row] : 1u;
+        c.reserved = 0;
+        p.out_chunks[at + j] = c;
+        for (uint32_t w = 0; w < p.W; ++w) p.out_chunk_words[(uint64_t)(at + j) * p.W + w] = p.col[w][row];
     }
 }
 
@@ -316,13 +374,11 @@ hipError_t queue_batch(const Buffers& b, const BatchArgs& a, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipError_t e = hipMemsetAsync(a.info, 0, INFO_WORDS * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
     const size_t off = (size_t)a.pos * a.k;
     MarkParams mp{b.rec + off, a.cnt, b.best + off, b.nbest + a.pos, b.freq_q + a.pos, b.unknown + a.pos, a.info, a.k, a.h_max, a.dup_limit, log2_slots(a.k)};
     const size_t lds = ((size_t)1 << mp.log2s) * 12;
     hipLaunchKernelGGL(mark_kernel, dim3(a.m), dim3(BLOCK), lds, stream, mp);
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(BLOCK), 0, stream, b.nbest + a.pos, b.offs + a.pos, a.m, a.base, a.info);
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(BLOCK), 0, stream, b.nbest + a.pos, b.unknown + a.pos, b.offs + a.pos, a.m, a.base, a.info);
     CompactParams cp{b.rec + off, b.best + off, b.offs + a.pos, b.c_asset[0], b.c_entry[0], a.k, a.pos};
     hipLaunchKernelGGL(compact_kernel, dim3(a.m), dim3(BLOCK), 0, stream, cp);
     return hipGetLastError();
@@ -333,11 +389,16 @@ hipError_t queue_score(Buffers& b, const ScoreArgs& a, hipStream_t stream) {
     size_t bytes = b.temp_bytes;
     e = rocprim::radix_sort_pairs(b.temp, bytes, b.c_asset[0], b.c_asset[1], b.c_entry[0], b.c_entry[1], a.entries, 0, 64, stream);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(b.n_assets, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    ScoreParams sp{b.c_asset[1], b.c_entry[1], b.rec, b.rows, a.freq_col, b.freq_q, a.sim_tab, a.idf_tab,
-                   b.score[0], b.order[0], b.matches, b.n_assets, a.entries, a.nq, a.k, a.dup_limit};
-    hipLaunchKernelGGL(score_kernel, dim3((a.entries + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, sp);
+    // (the outputs of the second sort are free until it runs: weights and query indices live there meanwhile)
+    WeightParams wp{b.c_entry[1], b.rec, b.rows, a.freq_col, b.freq_q, a.sim_tab, a.idf_tab, b.score[1], b.ws, b.order[1], b.idf_q,
+                    b.n_assets, a.entries, a.nq, a.k, a.dup_limit};
+    const uint32_t wn = a.entries > a.nq ? a.entries : a.nq;
+    hipLaunchKernelGGL(weights_kernel, dim3((wn + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, wp);
+    const uint32_t words = (a.nq + 63) / 64;
+    const uint32_t T = words <= 32 ? 256 : (words <= 64 ? 128 : 64);         // one LDS row of `words` u64 per thread, <= 64 KB per block
+    if (words > MAX_QUERY_SIMPRINTS / 64) return hipErrorInvalidValue;
+    ScoreParams sp{b.c_asset[1], b.score[1], b.ws, b.order[1], b.idf_q, b.score[0], b.order[0], b.matches, b.n_assets, a.entries, a.nq, words};
+    hipLaunchKernelGGL(score_kernel, dim3((a.entries + T - 1) / T), dim3(T), (size_t)words * T * 8, stream, sp);
     bytes = b.temp_bytes;
     e = rocprim::radix_sort_pairs_desc(b.temp, bytes, b.score[0], b.score[1], b.order[0], b.order[1], a.entries, 0, 64, stream);
     if (e != hipSuccess) return e;
@@ -345,10 +406,9 @@ hipError_t queue_score(Buffers& b, const ScoreArgs& a, hipStream_t stream) {
     ep.score = b.score[1]; ep.order = b.order[1]; ep.asset = b.c_asset[1]; ep.entry = b.c_entry[1]; ep.matches = b.matches;
     ep.n_assets = b.n_assets; ep.rec = b.rec; ep.rows = b.rows; ep.freq_col = a.freq_col;
     for (uint32_t w = 0; w < 4; ++w) ep.col[w] = a.col[w];
-    ep.first = b.order[0];           // the descending sort has consumed its input
     ep.out_results = a.out_results; ep.out_chunks = a.out_chunks; ep.out_chunk_words = a.out_chunk_words; ep.out_info = a.out_info;
     ep.limit = a.limit; ep.k = a.k; ep.W = a.W; ep.dup_limit = a.dup_limit;
-    hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(BLOCK), 0, stream, ep);
+    hipLaunchKernelGGL(emit_kernel, dim3(a.limit < a.entries ? a.limit : a.entries), dim3(BLOCK), 0, stream, ep);
     return hipGetLastError();
 }
 

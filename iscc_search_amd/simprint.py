@@ -16,7 +16,7 @@ from typing import Callable, List, Optional
 
 import numpy as np
 
-from iscc_search_amd._lib import MAX_K
+from iscc_search_amd._lib import MAX_K, MAX_SCORED_SIMPRINTS
 from iscc_search_amd.nphd import HipIndex128, words_to_key128
 
 CHUNK_POINTER_BYTES = 16
@@ -50,7 +50,7 @@ def _pack_simprints(simprints):
     # type: (list[bytes]) -> np.ndarray
     """[n, nbytes] uint8 of equal-length simprints in one copy (np.stack of 512 frombuffer views cost 0.8 ms); ragged input: numpy's own error."""
     nbytes = len(simprints[0])
-    if all(len(sp) == nbytes for sp in simprints):
+    if set(map(len, simprints)) == {nbytes}:
         return np.frombuffer(b"".join(simprints), dtype=np.uint8).reshape(len(simprints), nbytes)
     return np.stack([np.frombuffer(sp, dtype=np.uint8) for sp in simprints])
 
@@ -83,7 +83,7 @@ def coverage_quality_score(matched_simprints, doc_freq, queried):
     return coverage * quality
 
 
-@dataclass
+@dataclass(slots=True)
 class MatchedChunkRaw:
     query: bytes
     match: bytes
@@ -93,7 +93,7 @@ class MatchedChunkRaw:
     freq: int
 
 
-@dataclass
+@dataclass(slots=True)
 class SimprintMatchRaw:
     iscc_id_body: bytes
     score: float
@@ -152,7 +152,7 @@ class HipSimprintIndex:
         """
         if not simprints or len(self._index) == 0:
             return []
-        if (device_doc_freq or doc_freq_fn is None) and self._index.scores_on_device:
+        if (device_doc_freq or doc_freq_fn is None) and self._index.scores_on_device and len(simprints) <= MAX_SCORED_SIMPRINTS:
             return self._search_raw_device(simprints, limit, threshold, detailed, total_assets, DOC_FREQ_DUP_LIMIT if device_doc_freq else 0)
         return self._search_raw_host(simprints, limit, threshold, detailed, doc_freq_fn, total_assets, device_doc_freq)
 
@@ -185,22 +185,21 @@ class HipSimprintIndex:
                 f"limit {limit} x oversampling {self.oversampling_factor} = {limit * self.oversampling_factor} neighbours per simprint exceeds the "
                 f"{MAX_K} this backend returns, and a query simprint has that many stored chunks within the match threshold"
             )
-        out = []
+        # (columns as lists and positional construction: 520 chunk objects -- 13 assets x 40 matched simprints -- cost 0.67 ms built
+        #  field by field from structured rows, 0.28 ms this way)
+        body = [a.to_bytes(8, "big") for a in results["asset"].tolist()]
+        if not detailed:
+            return [SimprintMatchRaw(b, s, len(simprints), m, None) for b, s, m in zip(body, results["score"].tolist(), results["matches"].tolist())]
         nbytes = self.ndim // 8
-        raw_words = np.ascontiguousarray(words).astype(">u8").tobytes() if detailed else b""
         stride = (nbytes + 7) // 8 * 8
-        for r in results.tolist():
-            asset, score, matches, first = r
-            detail = None
-            if detailed:
-                detail = []
-                for j, (key_lo, qi, ham, freq, _) in enumerate(chunks[first : first + matches].tolist(), start=first):
-                    detail.append(MatchedChunkRaw(
-                        query=simprints[qi], match=raw_words[j * stride : j * stride + nbytes], score=1.0 - ham / self.ndim,
-                        offset=key_lo >> 32, size=key_lo & 0xFFFFFFFF, freq=freq,
-                    ))
-            out.append(SimprintMatchRaw(iscc_id_body=asset.to_bytes(8, "big"), score=score, queried=len(simprints), matches=matches, chunks=detail))
-        return out
+        raw = np.ascontiguousarray(words).astype(">u8").tobytes()
+        sim = [1.0 - h / self.ndim for h in range(self.ndim + 1)]
+        key_lo = chunks["key_lo"]
+        cols = zip(chunks["query"].tolist(), chunks["hamming"].tolist(), (key_lo >> np.uint64(32)).tolist(),
+                   (key_lo & np.uint64(0xFFFFFFFF)).tolist(), chunks["freq"].tolist())
+        detail = [MatchedChunkRaw(simprints[q], raw[j * stride : j * stride + nbytes], sim[h], o, z, f) for j, (q, h, o, z, f) in enumerate(cols)]
+        return [SimprintMatchRaw(b, s, len(simprints), m, detail[f : f + m])
+                for b, s, m, f in zip(body, results["score"].tolist(), results["matches"].tolist(), results["first_chunk"].tolist())]
 
     def _search_raw_host(self, simprints, limit, threshold, detailed, doc_freq_fn, total_assets, device_doc_freq):
         # type: (list[bytes], int, float, bool, Callable[[bytes], int] | None, int, bool) -> list[SimprintMatchRaw]

@@ -4,15 +4,18 @@ BASELINE config 5 end to end at its stated size: 10 M chunk fingerprints per tab
 fixed-``ndim`` table per simprint type), 128-bit chunk-pointer keys, for ndim = 64 / 128 / 256:
 
   * ``search_raw``  -- the approximate path of ``iscc_search/indexes/simprint/usearch_core.py:137-269`` on
-    ``HipSimprintIndex``: ONE batched exact Hamming search (count = limit x 20), stored vectors and document frequencies of the
-    matches from the device, IDF-weighted scoring on the host;
+    ``HipSimprintIndex``: ONE library call (``isccsearch_simprint_score``: batched exact Hamming search with count = limit x 20,
+    threshold, best chunk per asset and query, IDF-weighted scoring, sort and cut on the device), and beside it round 3's shape
+    of the same request (``_search_raw_host``: the neighbour lists cross PCIe and are scored by Python), which must return
+    the same assets with the same float64 scores;
   * ``search_exact`` -- the hard-boundary collision search (``lmdb_ops.py:169-301``): range-limited lookups at distance 0.
 
 Every time is split into the DEVICE share (wall time inside the C-ABI calls: search, vector gather, frequency column) and the
 HOST share (everything else: query packing, match filtering, per-asset aggregation, scoring, object construction).
 
-usage (GPU box): python tools/bench_simprint.py [chunks per table, default 10000000] [ndim ...]
-   run under `rocprofv3 --kernel-trace --stats` for the per-kernel table committed as profiles/r03_kernel_stats_simprint.csv
+usage (GPU box): python tools/bench_simprint.py [--raw-only] [chunks per table, default 10000000] [ndim ...]
+   run under `rocprofv3 --kernel-trace --stats` with --raw-only (search_raw through the library alone) for the per-kernel
+   table committed as profiles/r04_kernel_stats_simprint.csv
 """
 import os
 import sys
@@ -31,7 +34,7 @@ CHUNKS_PER_ASSET = 40
 class DeviceClock:
     """Wall time spent inside the index's device entry points (each ends with the results on the host)."""
 
-    NAMES = ("search_arrays", "search_within", "get_many", "get_freq", "doc_freq")
+    NAMES = ("search_arrays", "search_within", "get_many", "get_freq", "doc_freq", "score_assets")
 
     def __init__(self, index):
         self.seconds = 0.0
@@ -70,8 +73,10 @@ def build(eng, ndim, n_chunks, rng):
 
 
 def main():
-    n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-    ndims = [int(a) for a in sys.argv[2:]] or [64, 128, 256]
+    raw_only = "--raw-only" in sys.argv
+    args = [a for a in sys.argv[1:] if a != "--raw-only"]
+    n_chunks = int(args[0]) if args else 10_000_000
+    ndims = [int(a) for a in args[1:]] or [64, 128, 256]
     eng = HipEngine(0)
     for item in filter(None, os.environ.get("ISCC_HIP_OPTS", "").split(",")):      # e.g. ISCC_HIP_OPTS=mfma=0
         eng.set_option(item.split("=")[0].strip(), int(item.split("=")[1]))
@@ -104,6 +109,13 @@ def main():
             total, dev, worst, res = timed(lambda: idx.search_raw(simprints, **kw))
             print(f"search_raw   nq={nq:3d} count=400: {total * 1e3:7.2f} ms = device {dev * 1e3:6.2f} + host {(total - dev) * 1e3:6.2f} (slowest of {reps}: {worst * 1e3:.2f}); "
                   f"{len(res)} assets, top score {res[0].score:.4f}")
+            if raw_only:
+                continue
+            if nq <= 512 and (ndim != 64 or nq <= 64):       # (64-bit random fingerprints: 200 000 matched assets, seconds of Python)
+                host_kw = dict(limit=20, threshold=0.75, detailed=True, doc_freq_fn=None, total_assets=n_assets, device_doc_freq=True)
+                total_h, dev_h, worst_h, res_h = timed(lambda: idx._search_raw_host(simprints, **host_kw))
+                same = [(r.iscc_id_body, r.score, r.matches) for r in res] == [(r.iscc_id_body, r.score, r.matches) for r in res_h]
+                print(f"  scored on the host   : {total_h * 1e3:7.2f} ms = device {dev_h * 1e3:6.2f} + host {(total_h - dev_h) * 1e3:6.2f}; same assets and scores: {same}")
             exact_q = [bytes(r) for r in first[:nq]]
             idx.search_exact(exact_q, limit=20, threshold=0.0, detailed=True)
             clock.take()
