@@ -59,6 +59,8 @@ def valu_peak_gtriples(words):
     """(row, query, word) triples per second at full VALU issue: 64 lanes / ((4 + 0.5 / W) instructions x 4 cycles) per SIMD."""
     return SIMDS * CLOCK_HZ * 64 / ((4.0 + 0.5 / words) * 4.0) / 1e9
 PMC_PROFILE = os.path.join("profiles", "r03_pmc_fetch_size.json")
+if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_fetch_size.json")):
+    PMC_PROFILE = os.path.join("profiles", "r04_pmc_fetch_size.json")
 
 
 def splitmix64(x):
@@ -68,13 +70,17 @@ def splitmix64(x):
     return x ^ (x >> 31)
 
 
-def make_queries(nq, rows, words):
-    """random queries; every 4th is a stored code with f in {0,1,3,7} low bits flipped."""
+def make_queries(nq, rows, words, batch=0):
+    """
+    SURVEY.md section 8d: random queries; every 4th is a stored code with f in {0,1,3,7} low bits flipped.  `batch` b draws from
+    seeds SEED_Q + 1000 b / SEED_P + 1000 b: the timed region rotates through several DISTINCT batches.
+    """
     q = np.zeros((nq, words), dtype=np.uint64)
     planted = {}
+    seed_q, seed_p = SEED_Q + 1000 * batch, SEED_P + 1000 * batch
     for j in range(nq):
         if j % 4 == 0:
-            r = splitmix64(SEED_P + j) % rows
+            r = splitmix64(seed_p + j) % rows
             f = (0, 1, 3, 7)[(j // 4) % 4]
             for w in range(words):
                 q[j, w] = splitmix64(SEED_CODES + 4 * r + w)
@@ -82,7 +88,7 @@ def make_queries(nq, rows, words):
             planted[j] = (r, bin(f).count("1"))
         else:
             for w in range(words):
-                q[j, w] = splitmix64(SEED_Q + 4 * j + w)
+                q[j, w] = splitmix64(seed_q + 4 * j + w)
     return q, planted
 
 
@@ -168,6 +174,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=100_000_000, help="total rows of the index (all ranks together)")
     ap.add_argument("--queries", type=int, default=1024, help="queries per step")
+    ap.add_argument("--batches", type=int, default=8, help="distinct query batches the steps rotate through (gate, settle, warm-up, timed)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nbytes", type=int, default=8, help="code length in bytes (8 = 64-bit)")
     ap.add_argument("--metric", choices=["hamming", "nphd"], default="hamming", help="table metric (nphd: every row --nbytes long, queries too)")
@@ -240,44 +247,61 @@ def main():
     table.add_synthetic(args.nbytes, hi - lo, SEED_CODES, first_row=lo, key_base=0)
     sharded = ShardedTable(HipShardOps(table, device), always_gather=args.force_collective)
 
-    q, planted = make_queries(args.queries, args.rows, words)
+    # Several DISTINCT batches, taken in rotation by every step of the run (VERDICT r3 item 2 / ADVICE r3): a step starts under the
+    # k-th distance the PREVIOUS batch ended at (the engine's threshold hint), so identical batches would make that hint exact.
+    n_batches = max(1, args.batches)
+    batches = [make_queries(args.queries, args.rows, words, b) for b in range(n_batches)]
+    q = batches[0][0]
+    turn = [0]
 
     def step():
-        return sharded.search(q, q_nbytes, args.k)
+        b = turn[0] % n_batches
+        turn[0] += 1
+        return b, sharded.search(batches[b][0], q_nbytes, args.k)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # correctness gate outside the timed region: planted neighbours must come back first; the full answer is kept and
-    # compared with the oracle's below (cpu_baseline)
-    first = step()
-    keys, ham, pbits, cnt = first
-    for j, (r, f) in planted.items():
-        assert int(cnt[j]) == min(args.k, args.rows), (j, cnt[j])
-        assert int(ham[j, 0]) <= f, f"planted neighbour of query {j} not found: {ham[j, :3]} vs {f}"
-        if f == 0:
-            assert int(keys[j, 0]) == r or int(ham[j, 0]) == 0
-    assert np.all(np.diff(ham.astype(np.int64), axis=1)[:, : args.k - 1] >= 0), "results not sorted"
+    # correctness gate outside the timed region, EVERY batch once: planted neighbours must come back first, lists sorted and
+    # full; the answers are kept -- two batches are compared with the oracle's below (cpu_baseline), and whatever a measured
+    # leg returns for a batch last must equal its gate answer
+    gate = []
+    for b in range(n_batches):
+        _, ans = step()
+        keys, ham, pbits, cnt = ans
+        for j, (r, f) in batches[b][1].items():
+            assert int(cnt[j]) == min(args.k, args.rows), (b, j, cnt[j])
+            assert int(ham[j, 0]) <= f, f"batch {b}: planted neighbour of query {j} not found: {ham[j, :3]} vs {f}"
+            if f == 0:
+                assert int(keys[j, 0]) == r or int(ham[j, 0]) == 0
+        assert np.all(np.diff(ham.astype(np.int64), axis=1)[:, : args.k - 1] >= 0), "results not sorted"
+        gate.append(ans)
+    first = gate[0]
+    batches_compared = set()
 
     def measure(steps):
-        """`steps` steps with per-launch HIP events; returns (seconds, statistics).  The LAST step's answer must equal `first`."""
+        """`steps` steps with per-launch HIP events; returns (seconds, statistics).  Every batch's LAST answer must equal its gate answer."""
         fence()
         engine.stats(reset=True)
         if not args.no_profile:
             engine.set_option("profile", 1)
         fence()
+        last = {}
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = step()
+            b, out = step()
+            last[b] = out
         fence()
         el = time.perf_counter() - t0
         engine.set_option("profile", 0)
         st = engine.stats(reset=True)
-        for name, a, b in zip(("keys", "hamming", "prefix_bits", "count"), out, first):
-            if not np.array_equal(a, b):
-                raise SystemExit(f"PARITY FAILURE: the last measured step returned different {name} than the gate step")
+        for b, out in last.items():
+            for name, x, y in zip(("keys", "hamming", "prefix_bits", "count"), out, gate[b]):
+                if not np.array_equal(x, y):
+                    raise SystemExit(f"PARITY FAILURE: the last measured step of batch {b} returned different {name} than its gate step")
+            batches_compared.add(b)
         return el, st
 
     def max_over_ranks(seconds):
@@ -345,6 +369,7 @@ def main():
         extra["threshold_hint"] = {
             "steps_started_under_a_hint": int(st["spec_hits"]), "hints_that_did_not_hold": int(st["spec_misses"]),
             "what": "steps of the timed region whose thresholds started at the previous step's worst k-th distance + 2 (verified; exact either way)",
+            "distinct_batches_in_rotation": n_batches,
             "value_without_hints": args.queries * min(args.steps, 10) / el0,
             "ms_per_step_without_hints": el0 / min(args.steps, 10) * 1e3,
             "without_hints": "engine option speculate = 0: bootstrap sample + single pass (batches <= 128 queries: bootstrap + levels), same process, after the timed region",
@@ -399,19 +424,33 @@ def main():
             "code_bits": args.nbytes * 8,
             "k": args.k,
             "queries_per_step": args.queries,
+            "distinct_query_batches": n_batches,
             "queries_per_pass": args.tq,
             "scan": "FP4 MFMA" if mfma_on else "XOR + popcount",
             "parallelism": f"row-shard x{world}, one all-gather of per-shard top-k",
         },
         "roofline": roof,
         "fallback_queries": st["fallback_queries"],
+        # every batch of the rotation was gated before the timed region; these batches' last measured answers were compared with
+        # their gate answers (all legs together)
+        "batches_gated": n_batches,
+        "batches_compared_after_measurement": sorted(batches_compared),
     }
+    if dist.is_initialized():
+        # what the communicator itself reports (a SCALE record can then show that RCCL saw N ranks)
+        out["world_size_seen"] = dist.get_world_size()
+        out["collective_backend"] = dist.get_backend()
+        try:
+            out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # pragma: no cover - depends on the torch build
+            out["rccl_version"] = f"unavailable ({type(e).__name__})"
     out.update(extra)
 
     if rank == 0 and world == 1 and not args.no_other_configs and not args.no_cpu_baseline and args.nbytes == 8 and not nphd:
         out["other_configs"] = other_configs(engine, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, q, words, first)
+        second = (batches[1][0], gate[1]) if n_batches > 1 else None
+        out["cpu_baseline"] = cpu_baseline(args, q, words, first, second)
         out["parity_checked_queries"] = out["cpu_baseline"]["parity_checked_queries"]
 
     sys.stdout.flush()
@@ -531,11 +570,112 @@ def other_configs(engine, args):
                          "roofline": None if roof is None else {k_: roof[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}}
         finally:
             t.drop()
+    out["config5_end_to_end"] = config5_end_to_end(engine, rows5)
+    out["config1_protocol"] = config1_protocol()
     return out
 
 
-def cpu_baseline(args, q, words, gpu):
-    """The oracle (CPU restatement of the same exact search) on the host cores, bounded to ~10-30 s; its answers check the GPU's."""
+def config5_end_to_end(engine, chunks):
+    """
+    BASELINE config 5 through the simprint interface (`UsearchSimprintIndex.search_raw`, usearch_core.py:137-269): one table of
+    `chunks` 128-bit chunk fingerprints (40 per asset, 128-bit chunk-pointer keys), 512 query simprints, limit 20 x oversampling 20
+    = 400 neighbours each, threshold 0.75, chunk detail, device document frequencies.  ONE library call per request
+    (isccsearch_simprint_score): search, threshold, best chunk per asset and query, IDF-weighted scores, sort, cut -- all on the device.
+    Checked once against the same request scored on the host from the neighbour lists (round 3's path): equal assets, equal float64 scores.
+    """
+    from iscc_search_amd.simprint import HipSimprintIndex
+
+    per_asset, nq, reps = 40, 512, 9
+    rng = np.random.default_rng(0)
+    idx = HipSimprintIndex(engine, ndim=128)
+    try:
+        first = None
+        for lo in range(0, chunks, 1 << 20):
+            n = min(1 << 20, chunks - lo)
+            rows = np.arange(lo, lo + n, dtype=np.uint64)
+            keys = np.stack([rows // np.uint64(per_asset) + np.uint64(1),
+                             ((rows % np.uint64(per_asset)) * np.uint64(100) << np.uint64(32)) | np.uint64(100)], axis=1)
+            vecs = rng.integers(0, 256, size=(n, 16), dtype=np.uint8)
+            idx._index.add(keys, vecs, trusted_unique=True)
+            if first is None:
+                first = vecs[:nq].copy()
+        first[:, 0] ^= 3                                          # two flipped bits: near, not equal
+        simprints = [bytes(r) for r in first]
+        kw = dict(limit=20, threshold=0.75, detailed=True, total_assets=chunks // per_asset, device_doc_freq=True)
+        inner, inside = idx._index.score_assets, [0.0]
+
+        def timed_call(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return inner(*a, **k)
+            finally:
+                inside[0] += time.perf_counter() - t0
+
+        idx._index.score_assets = timed_call
+        res = idx.search_raw(simprints, **kw)                     # builds the frequency column
+        rows_t = []
+        for _ in range(reps):
+            inside[0] = 0.0
+            t0 = time.perf_counter()
+            res = idx.search_raw(simprints, **kw)
+            rows_t.append((time.perf_counter() - t0, inside[0]))
+        rows_t.sort()
+        total, dev = rows_t[reps // 2]
+        host = idx._search_raw_host(simprints, 20, 0.75, True, None, chunks // per_asset, True)
+        same = [(r.iscc_id_body, r.score, r.matches) for r in res] == [(r.iscc_id_body, r.score, r.matches) for r in host]
+        if not same:
+            raise SystemExit("PARITY FAILURE (config5_end_to_end): device scoring differs from the host scoring of the same neighbour lists")
+        return {"workload": f"{chunks} x 128-bit chunk fingerprints of {chunks // per_asset} assets, {nq} query simprints, limit 20 x oversampling 20, "
+                            "threshold 0.75, chunk detail, device document frequencies (search_raw end to end)",
+                "ms_per_request": total * 1e3, "ms_inside_the_library": dev * 1e3, "ms_python": (total - dev) * 1e3,
+                "requests_per_s": 1.0 / total, "query_simprints_per_s": nq / total, "assets_returned": len(res),
+                "scores_equal_host_scoring": same, "reps": reps, "statistic": "median"}
+    finally:
+        idx.close()
+
+
+def config1_protocol(n_assets=2500, n_queries=200):
+    """
+    BASELINE config 1 through the real backend: 10 000 random 64-bit units (2 500 assets x 4) via IsccIndexProtocol on the GPU
+    (HipIndexManager: `add_assets` iscc_search/indexes/usearch/index.py:194-537, `search_assets` :735-881), one thread.
+    """
+    from iscc_search_amd import codec
+    from iscc_search_amd.index import HipIndexManager
+    from iscc_search_amd.schema import IsccEntry, IsccIndex, IsccQuery
+
+    rng = np.random.default_rng(0)
+    assets = []
+    for i in range(n_assets):
+        units = [codec.encode_unit(mt, 0, 0, rng.integers(0, 256, size=8, dtype=np.uint8).tobytes())
+                 for mt in (codec.MT_META, codec.MT_CONTENT, codec.MT_DATA, codec.MT_INSTANCE)]
+        assets.append(IsccEntry(iscc_id=codec.iscc_id_from_int(((1_000_000 + i) << 12) | (i & 0xFFF), 0), iscc_code=codec.gen_iscc_code(units), units=units))
+    m = HipIndexManager("hip:///")
+    try:
+        m.create_index(IsccIndex(name="c1"))
+        t0 = time.perf_counter()
+        for i in range(0, n_assets, 500):
+            m.add_assets("c1", assets[i : i + 500])
+        add_s = time.perf_counter() - t0
+        queries = [IsccQuery(iscc_code=a.iscc_code) for a in assets[:n_queries]]
+        m.search_assets("c1", queries[0], limit=10)
+        t0 = time.perf_counter()
+        for qy in queries:
+            r = m.search_assets("c1", qy, limit=10)
+            if r.global_matches[0].score != 1.0:
+                raise SystemExit("PARITY FAILURE (config1_protocol): an indexed asset is not its own best match")
+        search_s = time.perf_counter() - t0
+    finally:
+        m.close()
+    return {"workload": f"{n_assets} assets x 4 units = {n_assets * 4} random 64-bit ISCC-UNITs through HipIndexManager (hip:///), one thread",
+            "add_assets_per_s": n_assets / add_s, "search_assets_per_s": n_queries / search_s, "ms_per_search": search_s / n_queries * 1e3,
+            "units_per_query": 4, "limit": 10}
+
+
+def cpu_baseline(args, q, words, gpu, second=None):
+    """
+    The oracle (CPU restatement of the same exact search) on the host cores, bounded to ~10-30 s; its answers check the GPU's for
+    the first batch of the rotation and, `second` = (queries, GPU answer), for up to 64 queries of another one.
+    """
     from oracle import oracle_num_threads, oracle_splitmix64_fill, oracle_topk
 
     rows = args.rows
@@ -572,6 +712,14 @@ def cpu_baseline(args, q, words, gpu):
         if not np.array_equal(g[:nq], e):
             bad = int(np.nonzero(np.any((g[:nq] != e).reshape(nq, -1), axis=1))[0][0])
             raise SystemExit(f"PARITY FAILURE: GPU {name} differ from the oracle for query {bad}: {g[bad]} vs {e[bad]}")
+    second_checked = 0
+    if second is not None:
+        q2, gpu2 = second
+        second_checked = min(64, len(q2), nq)
+        exp2 = run(q2[:second_checked], threads)
+        for name, g, e in zip(("keys", "hamming", "prefix_bits", "count"), gpu2, exp2):
+            if not np.array_equal(g[:second_checked], e):
+                raise SystemExit(f"PARITY FAILURE: GPU {name} of the second query batch differ from the oracle")
     # one core, on a 10 M-row slice (scaled linearly to the full table; labelled as extrapolated)
     slice_rows = min(rows, 10_000_000)
     t1 = time.perf_counter()
@@ -589,7 +737,8 @@ def cpu_baseline(args, q, words, gpu):
                   f"the CPUs this process may use; rows split across threads, cache-blocked over all queries)",
         "GBs": nq * reps * rows * 8 * words / dt / 1e9,
         "parity_checked_queries": nq,
-        "parity": f"keys, hamming, prefix_bits and counts of the GPU's answer to the first {nq} queries of the step are bit-identical to the oracle's",
+        "parity_checked_queries_second_batch": second_checked,
+        "parity": f"keys, hamming, prefix_bits and counts of the GPU's answer to the first {nq} queries of batch 0 (and {second_checked} of batch 1) are bit-identical to the oracle's",
         "py_memory_style": py_memory_style(),
         "usearch": "unavailable (iscc-usearch 0.8.1 / usearch-iscc 2.24.6 wheels are not in the image and cannot be installed offline; not estimated)",
     }

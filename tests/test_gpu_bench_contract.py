@@ -67,3 +67,23 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     hint = out["threshold_hint"]
     assert hint["steps_started_under_a_hint"] + hint["hints_that_did_not_hold"] >= 1
     assert hint["value_without_hints"] > 0 and hint["ms_per_step_without_hints"] > 0
+    # round 4: the steps rotate through DISTINCT query batches, each gated once and compared after every
+    # measured leg, two of them against the oracle; config 5 end to end and config 1 through the protocol ride in other_configs
+    assert out["config"]["distinct_query_batches"] == 8 and out["batches_gated"] == 8 and hint["distinct_batches_in_rotation"] == 8
+    assert len(out["batches_compared_after_measurement"]) >= 3
+    assert cpu["parity_checked_queries_second_batch"] == 64
+    c5 = out["other_configs"]["config5_end_to_end"]
+    assert c5["scores_equal_host_scoring"] is True and c5["ms_per_request"] > 0 and c5["ms_inside_the_library"] <= c5["ms_per_request"]
+    c1 = out["other_configs"]["config1_protocol"]
+    assert c1["add_assets_per_s"] > 0 and c1["search_assets_per_s"] > 0
+
+
+def test_a_one_rank_collective_run_reports_what_the_communicator_saw():
+    proc = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "2000000", "--steps", "3", "--warmup", "1", "--force-collective",
+         "--no-cpu-baseline", "--no-extra-legs"],
+        capture_output=True, text=True, timeout=600, cwd=ROOT,
+    )
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.strip()][-1])
+    assert out["world_size_seen"] == 1 and out["collective_backend"] == "nccl" and out["rccl_version"]
