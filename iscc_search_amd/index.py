@@ -560,7 +560,7 @@ class HipIndexManager:
         self._shard_backend = qs.get("backend", ["nccl"])[0]
         self._shard_same_gpu = qs.get("same_gpu", ["0"])[0] == "1"
         self._shard_engine_factory = shard_engine_factory
-        self._leader = None
+        self._leading = False          # this manager drives a leader front (shard_front.LeaderEngine) as its engine
         # hip:///            -> volatile (like memory://)
         # hip:///abs/path    -> snapshots under that directory: loaded lazily, written by flush()/close()
         self.base_path = parsed.path if parsed.path not in ("", "/") else None
@@ -580,28 +580,40 @@ class HipIndexManager:
                 if INDEX_NAME_RE.match(name) and os.path.exists(os.path.join(self.base_path, name, "index.json")):
                     self._on_disk.add(name)
 
-    def _lead(self):
-        """The leader front of a sharded index opened by ONE process (None: unsharded, an injected engine, or SPMD under a launcher)."""
-        if self.devices == 1 or self._engine is not None:
-            return None
-        if self._leader is None:
-            import torch.distributed as dist
+    def _leads(self):
+        """
+        Whether this manager is the ONE calling process of a sharded index (``shard_front.LeaderEngine``: it starts the other
+        ranks itself) -- as opposed to unsharded, an injected engine, or one rank of a launcher's SPMD group.
+        """
+        if self.devices == 1 or (self._engine is not None and not self._leading):
+            return False
+        if self._leading:
+            return True
+        import torch.distributed as dist
 
-            if dist.is_initialized():
-                return None
-            from iscc_search_amd.shard_front import ShardLeader
+        from iscc_search_amd import shard_front
 
-            with self._lock:
-                if self._leader is None:
-                    self._leader = ShardLeader(self._uri, self.devices, backend=self._shard_backend, engine_factory=self._shard_engine_factory,
-                                               same_gpu=self._shard_same_gpu)
-        return self._leader
+        # a process group that exists and is NOT a leader front's belongs to a launcher: SPMD
+        return not dist.is_initialized() or shard_front.leads_this_process()
+
+    @property
+    def _leader(self):
+        """The leader front this manager drives (None before its first use and in every other mode)."""
+        return self._engine if self._leading else None
 
     def _get_engine(self):
         if self._engine is None:
             from iscc_search_amd.engine import HipEngine   # raises loudly without library / GPU
 
-            if self.devices > 1:
+            if self.devices > 1 and self._leads():
+                from iscc_search_amd.shard_front import leader_engine
+
+                with self._lock:
+                    if self._engine is None:
+                        self._engine = leader_engine(self.devices, backend=self._shard_backend, engine_factory=self._shard_engine_factory,
+                                                     same_gpu=self._shard_same_gpu)
+                        self._leading = True
+            elif self.devices > 1:
                 import torch.distributed as dist
 
                 from iscc_search_amd.sharded_engine import ShardedEngine
@@ -609,7 +621,7 @@ class HipIndexManager:
                 if not dist.is_initialized() or dist.get_world_size() != self.devices:
                     raise ValueError(
                         f"hip:///?devices={self.devices}: this rank's engine needs the process group of {self.devices} ranks (one per GPU); "
-                        f"a single calling process gets it from shard_front.ShardLeader, a launcher from torch.distributed.run"
+                        f"a single calling process gets it from shard_front.LeaderEngine, a launcher from torch.distributed.run"
                     )
                 local = int(os.environ.get("LOCAL_RANK", dist.get_rank()))
                 self._engine = ShardedEngine(HipEngine(local), device=f"cuda:{local}")
@@ -636,15 +648,16 @@ class HipIndexManager:
             return json.load(f).get("assets", 0)
 
     # Every public method runs `_guarded`:
-    #   * a sharded index opened by ONE process hands the call to the leader front, which broadcasts it to the shard workers and
-    #     runs it on this process's own rank-0 manager (shard_front.py) -- the leader's lock orders all requests;
+    #   * a sharded index opened by ONE process: the host logic runs here, alone, over the leader front's engine, which broadcasts
+    #     every TABLE operation to the shard workers in its own order and combines the searches of concurrent callers
+    #     (shard_front.py) -- no manager-wide lock, as on one GPU; a front that is down fails every call, also those that need no table;
     #   * a sharded index under a launcher (SPMD) takes `_spmd` around the WHOLE method: flush, close, the lazy snapshot load in
     #     `_index` and delete_index reach collectives just as add / search do;
     #   * one GPU: no extra lock, searches of concurrent callers are combined by the engine.
     def _guarded(self, method, impl, *args, **kwargs):
-        lead = self._lead()
-        if lead is not None:
-            return lead.call(method, *args, **kwargs)
+        if self._leads():
+            self._get_engine().check()
+            return impl(*args, **kwargs)
         if self._spmd is not None:
             with self._spmd:
                 return impl(*args, **kwargs)
@@ -745,11 +758,18 @@ class HipIndexManager:
 
     def close(self):
         # type: () -> None
-        if self._leader is not None:
-            self._leader.close()
-            self._closed = True
-            return
-        if self._spmd is not None:
+        if self._leading:
+            if self._engine is not None and self._engine.broken is not None:
+                # nothing can be flushed through a front that is down: release what is left of it
+                with self._lock:
+                    if not self._closed:
+                        self._closed = True
+                        self._indexes.clear()
+                        self._engine.close()
+                        self._engine = None
+                return
+            return self._close()
+        if self._spmd is not None and not self._leads():
             with self._spmd:
                 return self._close()
         return self._close()

@@ -262,6 +262,19 @@ class HipHammingIndex:
     close = reset
 
 
+def table_rows(table, chunk_rows=1 << 20):
+    """(16-byte key, code bytes) of every row of a table with 128-bit keys, segment by segment."""
+    for nbytes, total in table.segments().items():
+        for first in range(0, total, chunk_rows):
+            n = min(chunk_rows, total - first)
+            keys, cols = table.export_rows(nbytes, first, n)
+            kb = words_to_key128(keys)
+            raw = np.ascontiguousarray(cols.T).astype(">u8").tobytes()
+            stride = cols.shape[0] * 8
+            for i in range(n):
+                yield kb[i], raw[i * stride : i * stride + nbytes]
+
+
 def key128_to_words(keys):
     # type: (list[bytes] | np.ndarray) -> np.ndarray
     """16-byte big-endian keys -> uint64 [n, 2] (hi, lo)."""
@@ -426,15 +439,9 @@ class HipIndex128:
 
     def rows(self, chunk_rows=1 << 20):
         """Iterate (key bytes, vector bytes) over every stored row (snapshot restore of host-side maps)."""
-        for nbytes, total in self._table.segments().items():
-            for first in range(0, total, chunk_rows):
-                n = min(chunk_rows, total - first)
-                keys, cols = self._table.export_rows(nbytes, first, n)
-                kb = words_to_key128(keys)
-                raw = np.ascontiguousarray(cols.T).astype(">u8").tobytes()
-                stride = cols.shape[0] * 8
-                for i in range(n):
-                    yield kb[i], raw[i * stride : i * stride + nbytes]
+        if hasattr(self._table, "rows"):          # a leader-front table gathers the rows of every shard itself
+            return self._table.rows()
+        return table_rows(self._table, chunk_rows)
 
     def reset(self):
         self._table.drop()

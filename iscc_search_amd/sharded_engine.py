@@ -21,8 +21,9 @@ SPMD discipline (as for any ``torch.distributed`` program): every rank must make
 to get that:
 
 * ONE calling process (the reference's server and CLI): ``HipIndexManager("hip:///path?devices=N")`` constructed where no
-  process group exists becomes the leader of ``shard_front.ShardLeader``, starts the other ranks itself and broadcasts every
-  protocol call to them under one lock -- the order is the leader's, whatever the caller's threads do;
+  process group exists becomes the leader (``shard_front.LeaderEngine``): it starts the other ranks itself, runs the host
+  logic alone and broadcasts every TABLE operation to the workers, which serve them on their ``ShardedHipTable`` -- the order
+  is the leader's, whatever the caller's threads do;
 * ``python -m torch.distributed.run --nproc-per-node N script.py`` where the script itself makes identical calls on every rank
   (``bench.py``): then each rank's manager holds one lock around EVERY protocol method (also flush, close, the lazy snapshot
   load and delete_index: all of them reach collectives), which keeps one rank's threads from interleaving two requests'
@@ -150,14 +151,18 @@ class ShardedHipTable:
             self.local.add(keys[mine], np.asarray(words, dtype=np.uint64)[mine], None if nbytes is None else np.asarray(nbytes)[mine],
                            trusted_unique=trusted_unique)
 
-    def remove(self, keys):
+    def remove_local(self, keys):
+        """This rank's part of ``remove`` (no collective): how many of the keys it held and removed."""
         keys = np.asarray(keys, dtype=np.uint64)
         removed = 0
         if keys.shape[0]:
             mine = self._mine(keys)
             if mine.any():
                 removed = self.local.remove(keys[mine])
-        return int(self.engine.all_reduce(np.array([removed], dtype=np.int64))[0])
+        return removed
+
+    def remove(self, keys):
+        return int(self.engine.all_reduce(np.array([self.remove_local(keys)], dtype=np.int64))[0])
 
     # -- lookups answered by the owner -----------------------------------------------------------------------
     def contains(self, keys):
@@ -229,6 +234,12 @@ class ShardedHipTable:
 
     def export_rows(self, nbytes, first_row, n):
         return self.local.export_rows(nbytes, first_row, n)
+
+    def gathered_rows(self):
+        """Sorted (key bytes, code bytes) of the rows of EVERY shard (a collective; restore of old snapshots only)."""
+        from iscc_search_amd.nphd import table_rows
+
+        return sorted(r for part in self.engine.all_gather_object(list(table_rows(self.local))) for r in part)
 
     def add_columns(self, nbytes, keys, cols, trusted_unique=False):
         self.local.add_columns(nbytes, keys, cols, trusted_unique=trusted_unique)

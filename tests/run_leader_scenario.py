@@ -2,7 +2,7 @@
 Runs in a process of its own (tests/test_shard_leader.py): ONE process constructs ``HipIndexManager("hip://...?devices=N")``,
 which becomes the leader of its shard workers, and drives the index through protocol calls only.
 
-usage: run_leader_scenario.py <uri> <engine factory | -> <out.json> [kill]
+usage: run_leader_scenario.py <uri> <engine factory | -> <out.json> [kill | idle | threads | outcomes]
 """
 
 import json
@@ -105,6 +105,94 @@ def main():
             again = str(e)
         m.close()
         out = {"first": result, "again": again, "seconds": time.time() - t0}
+    elif len(sys.argv) > 4 and sys.argv[4] == "idle":
+        # an idle front must outlive the deadline of the collective its workers wait in (ISCC_HIP_SHARD_TIMEOUT_S)
+        m = make()
+        m.create_index(IsccIndex(name="main"))
+        rng = np.random.default_rng(1)
+        assets = [make_asset(rng, i) for i in range(8)]
+        m.add_assets("main", assets)
+        idle = 2.2 * float(os.environ["ISCC_HIP_SHARD_TIMEOUT_S"])
+        time.sleep(idle)
+        r = m.search_assets("main", IsccQuery(iscc_code=assets[3].iscc_code), limit=3)
+        out = {"idle_seconds": idle, "top": r.global_matches[0].iscc_id, "want": assets[3].iscc_id, "score": r.global_matches[0].score}
+        m.close()
+    elif len(sys.argv) > 4 and sys.argv[4] == "threads":
+        # eight caller threads, as FastAPI's thread pool calls the sync protocol methods: every answer must be the single-threaded one
+        import threading
+
+        m = make()
+        m.create_index(IsccIndex(name="main"))
+        rng = np.random.default_rng(5)
+        assets = [make_asset(rng, i) for i in range(64)]
+        m.add_assets("main", assets)
+        queries = [IsccQuery(iscc_code=a.iscc_code) for a in assets]
+        dump = lambda r: json.dumps(r.model_dump(mode="json"), sort_keys=True)       # noqa: E731
+        want = [dump(m.search_assets("main", q, limit=5)) for q in queries]
+        got = [None] * len(queries)
+        errors = []
+
+        def worker(tid):
+            try:
+                for rep in range(3):
+                    for i in range(tid, len(queries), 8):
+                        got[i] = dump(m.search_assets("main", queries[i], limit=5))
+                    if tid == 0 and rep == 1:
+                        m.add_assets("main", [assets[0]])             # a writer between the searches (idempotent re-add)
+            except BaseException as e:      # noqa: BLE001
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        t0 = time.time()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        out = {"equal": got == want, "errors": errors, "seconds": time.time() - t0, "searches": 3 * len(queries)}
+        m.close()
+    elif len(sys.argv) > 4 and sys.argv[4] == "outcomes":
+        # a failure every rank raises alike goes to the caller and the front stays up; outcomes that differ take it down
+        m = make()
+        m.create_index(IsccIndex(name="main"))
+        rng = np.random.default_rng(1)
+        assets = [make_asset(rng, i) for i in range(8)]
+        m.add_assets("main", assets)
+        eng = m._leader
+        t = eng.open_table(0, 1, 8)
+        out = {}
+        try:
+            t.load(os.path.join(os.path.dirname(out_path), "no-such-snapshot"))
+            out["alike"] = "no error"
+        except ValueError as e:
+            out["alike"] = "ValueError: " + str(e)
+        out["still_up"] = m.search_assets("main", IsccQuery(iscc_code=assets[2].iscc_code), limit=3).global_matches[0].iscc_id == assets[2].iscc_id
+        for bad in (lambda: t.search(np.zeros((1, 2), dtype=np.uint64), None, 3), lambda: t.search(np.zeros((1, 1), dtype=np.uint64), None, 0),
+                    lambda: t.add(np.zeros((2, 2), dtype=np.uint64), np.zeros((2, 1), dtype=np.uint64))):
+            try:
+                bad()
+                out.setdefault("invalid", []).append("no error")
+            except ValueError as e:
+                out.setdefault("invalid", []).append("ValueError")
+        out["up_after_invalid"] = len(m.list_indexes()) == 1
+        # a snapshot only rank 0 can see: its shard directory exists, the other rank's does not
+        lone = os.path.join(os.path.dirname(out_path), "lonely")
+        t.add(np.arange(4, dtype=np.uint64), np.arange(4, dtype=np.uint64).reshape(4, 1))
+        t.save(lone)
+        import shutil
+
+        shutil.rmtree(os.path.join(lone, "shard-1-of-2"))
+        t2 = eng.open_table(0, 1, 8)
+        try:
+            t2.load(lone)
+            out["differ"] = "no error"
+        except RuntimeError as e:
+            out["differ"] = str(e)
+        try:
+            m.list_indexes()
+            out["after"] = "no error"
+        except RuntimeError as e:
+            out["after"] = str(e)
+        m.close()
     else:
         out = protocol_scenario(make)
     with open(out_path, "w") as f:

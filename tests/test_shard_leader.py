@@ -19,8 +19,8 @@ sys.path.insert(0, HERE)
 from run_leader_scenario import protocol_scenario  # noqa: E402
 
 
-def run_leader(uri, factory, out_path, *extra, timeout=600):
-    env = dict(os.environ)
+def run_leader(uri, factory, out_path, *extra, timeout=600, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
     env["PYTHONPATH"] = os.pathsep.join([HERE, os.path.dirname(HERE), env.get("PYTHONPATH", "")])
     proc = subprocess.run([sys.executable, os.path.join(HERE, "run_leader_scenario.py"), uri, factory, str(out_path), *extra],
                           capture_output=True, text=True, timeout=timeout, env=env)
@@ -50,3 +50,25 @@ def test_a_dead_worker_breaks_the_front_instead_of_hanging_it(tmp_path):
     assert out["first"].startswith("the sharded index is down"), out
     assert out["again"].startswith("the sharded index is down"), out
     assert out["seconds"] < 120, out
+
+
+def test_an_idle_front_outlives_the_collective_deadline(tmp_path):
+    """workers wait for the next request inside a collective with a deadline; the leader's heartbeat keeps it from expiring."""
+    out = run_leader(f"hip://{tmp_path}/sharded?devices=2&backend=gloo", "shard_factories:oracle", tmp_path / "idle.json", "idle",
+                     timeout=300, env_extra={"ISCC_HIP_SHARD_TIMEOUT_S": "4"})
+    assert out["idle_seconds"] > 8 and out["top"] == out["want"] and out["score"] == 1.0, out
+
+
+def test_eight_caller_threads_get_the_single_threaded_answers(tmp_path):
+    """the leader front combines concurrent callers; every thread's answer equals the sequential one."""
+    out = run_leader(f"hip://{tmp_path}/sharded?devices=2&backend=gloo", "shard_factories:oracle", tmp_path / "threads.json", "threads", timeout=300)
+    assert out["errors"] == [] and out["equal"] is True, out
+
+
+def test_outcomes_alike_reach_the_caller_outcomes_that_differ_end_the_front(tmp_path):
+    """errors are classified by what the RANKS report, not by exception type alone."""
+    out = run_leader(f"hip://{tmp_path}/sharded?devices=2&backend=gloo", "shard_factories:oracle", tmp_path / "outcomes.json", "outcomes", timeout=300)
+    assert out["alike"].startswith("ValueError") and out["still_up"] is True, out
+    assert out["invalid"] == ["ValueError"] * 3 and out["up_after_invalid"] is True, out
+    assert out["differ"].startswith("the sharded index is down") and "disagree" in out["differ"], out
+    assert out["after"].startswith("the sharded index is down"), out

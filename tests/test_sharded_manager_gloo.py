@@ -124,8 +124,17 @@ def test_sharded_manager_answers_like_the_unsharded_one(tmp_path):
     assert sum(locals_) == 60 and all(0 < n < 60 for n in locals_), locals_
 
 
-def test_devices_needs_a_process_group():
-    with pytest.raises(ValueError, match="needs the process group of 4 ranks"):
-        HipIndexManager("hip:///?devices=4")._get_engine()
+def test_a_sharded_index_without_gpus_fails_loudly():
+    """
+    ONE process asking for ``devices=4`` becomes the leader of a front (``shard_front.LeaderEngine``) and starts the other ranks
+    itself; on a box without GPUs the RCCL group cannot be formed: the call raises, the workers it had started are stopped, and
+    nothing pretends to be a sharded index (no CPU fallback).
+    """
+    from iscc_search_amd import shard_front
+
+    m = HipIndexManager("hip:///?devices=4")
+    with pytest.raises((ValueError, RuntimeError)):
+        m._get_engine()
+    assert m._engine is None and not shard_front.leads_this_process() and not dist.is_initialized()
     with pytest.raises(ValueError, match="devices must be >= 1"):
         HipIndexManager("hip:///?devices=0")
