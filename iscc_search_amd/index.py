@@ -25,6 +25,8 @@ import numpy as np
 
 from iscc_search_amd import codec
 from iscc_search_amd._lib import MAX_K
+
+INSTANCE_FIRST_K = 64   # records per query an INSTANCE prefix match asks for first (a full list is asked again up to MAX_K)
 from iscc_search_amd.engine import pack_bytes
 from iscc_search_amd.nphd import HipNphdIndex
 from iscc_search_amd.schema import (
@@ -298,7 +300,9 @@ class HipIndex:
         table = self._unit_tables.get(unit_type)
         if table is None:
             return {}
-        m = table.search_within(np.frombuffer(body, dtype=np.uint8), count=MAX_K, max_hamming=0)
+        m = table.search_within(np.frombuffer(body, dtype=np.uint8), count=INSTANCE_FIRST_K, max_hamming=0)
+        if len(m.keys) == INSTANCE_FIRST_K:      # the list may go on: ask for everything up to the cap
+            m = table.search_within(np.frombuffer(body, dtype=np.uint8), count=MAX_K, max_hamming=0)
         _check_instance_hits(len(m.keys), unit_type)
         return {int(key): 1.0 for key in m.keys}
 
@@ -317,14 +321,19 @@ class HipIndex:
                 continue
             words, nbytes = pack_bytes([unit.body], index._table.max_words)
             if unit.unit_type.startswith("INSTANCE_"):
-                requests.append((index._table, words, nbytes, MAX_K, 0))
+                # identity matches are few: a short list first (64 records per query to select, exchange between shards and unpack instead
+                # of 4 096); a list that comes back full is asked again up to the cap
+                requests.append((index._table, words, nbytes, INSTANCE_FIRST_K, 0))
             else:
                 requests.append((index._table, words, nbytes, _checked_limit(limit), None))
             plan.append(unit.unit_type)
         aggregated = {}  # type: Dict[int, Dict[str, float]]
-        for unit_type, (keys, ham, pbits, cnt) in zip(plan, self._engine.search_many(requests)):
+        for unit_type, request, (keys, ham, pbits, cnt) in zip(plan, requests, self._engine.search_many(requests)):
             c = int(cnt[0])
             if unit_type.startswith("INSTANCE_"):
+                if c == INSTANCE_FIRST_K:
+                    keys, ham, pbits, cnt = self._engine.search_many([request[:3] + (MAX_K, 0)])[0]
+                    c = int(cnt[0])
                 _check_instance_hits(c, unit_type)
                 for key in keys[0, :c]:
                     aggregated.setdefault(int(key), {})[unit_type] = 1.0

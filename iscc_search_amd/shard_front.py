@@ -15,10 +15,10 @@ Division of labour:
 * the WORKERS hold no host state of the index at all: they serve TABLE operations (open / add / remove / contains / get /
   size / search / search_within / doc_freq / get_freq / save / load / drop) on their shard (``sharded_engine.ShardedHipTable``),
   joining the collectives of each (local top-k -> ONE all-gather -> merge, owner lookups -> one small all-reduce);
-* a table operation travels as ONE broadcast on the gloo control group: a fixed 1 KB frame {op, table, counts, flags | inline
-  payload} -- keys, codes and queries as raw array bytes, no pickling; a second broadcast carries payloads beyond the frame;
+* a table operation travels as ONE write per worker on that worker's request PIPE: a 64-byte header {op, table, counts,
+  flags} + keys, codes and queries as raw array bytes -- no pickling, no collective, microseconds;
 * concurrent callers are COMBINED, as ``isccsearch_search`` combines them on one GPU: the first searching thread leads one
-  round, takes every request waiting on the same (table, k, radius), runs them as one broadcast + one collective step and
+  round, takes every request waiting on the same (table, k, radius), runs them as one request + one collective step and
   hands each caller its slice.  Everything else is serialised by the engine's lock, in the leader's order.
 
 Failure handling:
@@ -31,8 +31,9 @@ Failure handling:
 * a worker that dies is noticed by the watchdog thread, a leader-side fault marks the front broken: every further call raises
   ``RuntimeError("the sharded index is down: ...")``, the workers are stopped.  No process that has initialised the GPU is
   ever re-executed;
-* an IDLE front stays up: workers wait for the next frame inside a collective with a deadline, so the watchdog broadcasts a
-  no-op frame whenever nothing was sent for a third of that deadline.
+* an IDLE front stays up: a worker waits for its next request in a blocking pipe read, which has no deadline -- the process
+  group (whose collectives do carry one) is used only inside an operation; a leader that dies closes the pipes,
+  which ends the workers.
 
 The data path keeps its own backend: ``nccl`` (RCCL over xGMI) by default, ``gloo`` for CPU tests and for ranks that share
 one GPU (``backend=gloo`` in the URI's query or the constructor).
@@ -53,10 +54,9 @@ ENV_BACKEND = "ISCC_HIP_SHARD_BACKEND"
 ENV_SAME_GPU = "ISCC_HIP_SHARD_SAME_GPU"          # "1": every rank uses GPU 0 (rehearsal on a one-GPU box, backend gloo)
 ENV_TIMEOUT = "ISCC_HIP_SHARD_TIMEOUT_S"
 
+ENV_REQUEST_FD = "ISCC_HIP_SHARD_REQUEST_FD"      # the read end of this worker's request pipe
 # -- the wire format of one table operation ---------------------------------------------------------------------------
-FRAME_BYTES = 1024
 HEAD_WORDS = 8                                      # int64: op, table, n, a, b, c, payload bytes, sequence number
-INLINE_BYTES = FRAME_BYTES - 8 * HEAD_WORDS
 (OP_NOP, OP_SHUTDOWN, OP_OPEN, OP_DROP, OP_RESERVE, OP_ADD, OP_REMOVE, OP_CONTAINS, OP_GET, OP_SIZE, OP_SEARCH, OP_DOC_FREQ,
  OP_GET_FREQ, OP_SAVE, OP_LOAD, OP_SET_OPTION, OP_ROWS, OP_SEARCH_MANY) = range(18)
 # operations that end their local part with an exchange of outcomes (their local part holds no collective)
@@ -107,37 +107,58 @@ def pack(arrays):
     return b"".join(np.ascontiguousarray(a).tobytes() for a in arrays if a is not None)
 
 
-class Channel:
-    """Frames from the leader to every worker over the control group (``dist.broadcast`` of uint8 tensors)."""
+def _write_all(fd, data):
+    view = memoryview(data)
+    while view:
+        view = view[os.write(fd, view) :]
 
-    def __init__(self, dist, group):
+
+def _read_exact(fd, n):
+    parts = []
+    while n:
+        part = os.read(fd, min(n, 1 << 20))
+        if not part:
+            raise EOFError("the leader closed the request pipe")
+        parts.append(part)
+        n -= len(part)
+    return b"".join(parts)
+
+
+class Channel:
+    """
+    Requests from the leader to every worker, and the exchange of outcomes.
+
+    A request is a 64-byte header {op, table, n, a, b, c, payload bytes, sequence number} followed by its payload, written to
+    ONE PIPE PER WORKER (created before the workers are started, inherited by them).  A worker waits for its next request in a
+    plain blocking read: no deadline runs while the index is idle (the wait used to sit inside a gloo collective,
+    whose timeout took an idle index down), a pipe write costs microseconds where a gloo broadcast costs 0.1-0.3 ms, and a
+    leader that dies closes the pipe, which ends the worker.  The process group is used only INSIDE an operation.
+    """
+
+    def __init__(self, dist, group, write_fds=(), read_fd=None):
         import torch
 
         self.dist, self.group, self.torch = dist, group, torch
-        self.frame = torch.zeros(FRAME_BYTES, dtype=torch.uint8)
-        self.head = self.frame[: 8 * HEAD_WORDS].view(torch.int64)
+        self.write_fds, self.read_fd = list(write_fds), read_fd
         self.seq = 0
 
     def send(self, op, table=0, n=0, a=0, b=0, c=0, payload=b""):
         self.seq += 1
-        self.head[:] = self.torch.tensor([op, table, n, a, b, c, len(payload), self.seq], dtype=self.torch.int64)
-        inline = len(payload) <= INLINE_BYTES
-        if inline and payload:
-            self.frame[8 * HEAD_WORDS : 8 * HEAD_WORDS + len(payload)] = self.torch.frombuffer(bytearray(payload), dtype=self.torch.uint8)
-        self.dist.broadcast(self.frame, src=0, group=self.group)
-        if not inline:
-            self.dist.broadcast(self.torch.frombuffer(bytearray(payload), dtype=self.torch.uint8), src=0, group=self.group)
+        data = np.array([op, table, n, a, b, c, len(payload), self.seq], dtype=np.int64).tobytes() + payload
+        for fd in self.write_fds:
+            _write_all(fd, data)
 
     def recv(self):
-        self.dist.broadcast(self.frame, src=0, group=self.group)
-        op, table, n, a, b, c, nbytes, seq = (int(x) for x in self.head.tolist())
-        if nbytes <= INLINE_BYTES:
-            payload = self.frame[8 * HEAD_WORDS : 8 * HEAD_WORDS + nbytes].numpy().tobytes()
-        else:
-            big = self.torch.empty(nbytes, dtype=self.torch.uint8)
-            self.dist.broadcast(big, src=0, group=self.group)
-            payload = big.numpy().tobytes()
-        return op, table, n, a, b, c, payload
+        op, table, n, a, b, c, nbytes, _ = (int(x) for x in np.frombuffer(_read_exact(self.read_fd, 8 * HEAD_WORDS), dtype=np.int64))
+        return op, table, n, a, b, c, (_read_exact(self.read_fd, nbytes) if nbytes else b"")
+
+    def close(self):
+        for fd in self.write_fds:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        self.write_fds = []
 
     def outcomes_agree(self, code):
         """One tiny all-reduce: (every rank reported `code`?, the largest code).  All ranks call it at the same point of an operation."""
@@ -386,7 +407,6 @@ class LeaderEngine:
         self._users = 0
         self._tables = {}
         self._next_table = 1
-        self._last_frame = time.time()
         port = free_port()
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(devices))
         env[ENV_BACKEND], env[ENV_TIMEOUT] = backend, str(self.timeout_s)
@@ -400,9 +420,14 @@ class LeaderEngine:
         # fresh interpreters, started BEFORE this process makes its first GPU call (a process that has initialised the GPU must
         # not be the parent of an exec on this platform); each gets its rank through the environment
         self.workers = []
+        write_fds = []
         for rank in range(1, devices):
+            r, w = os.pipe()
             e = dict(env, RANK=str(rank), LOCAL_RANK=str(0 if same_gpu else rank))
-            self.workers.append(subprocess.Popen([sys.executable, "-m", "iscc_search_amd.shard_worker"], env=e))
+            e[ENV_REQUEST_FD] = str(r)
+            self.workers.append(subprocess.Popen([sys.executable, "-m", "iscc_search_amd.shard_worker"], env=e, pass_fds=(r,)))
+            os.close(r)
+            write_fds.append(w)
         for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE"):
             os.environ[k] = env[k]
         os.environ["RANK"] = "0"
@@ -416,14 +441,16 @@ class LeaderEngine:
             dist.init_process_group(backend=backend, rank=0, world_size=devices, timeout=datetime.timedelta(seconds=self.timeout_s), **kwargs)
             self.dist = dist
             self.engine, self.ctrl = build_rank_engine(engine_factory, same_gpu, self.timeout_s)
-            self.channel = Channel(dist, self.ctrl)
+            self.channel = Channel(dist, self.ctrl, write_fds=write_fds)
         except BaseException:
+            for fd in write_fds:
+                os.close(fd)
             self._stop_workers()
             raise
         self._watchdog = threading.Thread(target=self._watch, name="hip-shard-watchdog", daemon=True)
         self._watchdog.start()
 
-    # -- failure handling, heartbeat ----------------------------------------------------------------------------------
+    # -- failure handling --------------------------------------------------------------------------------------------
     def _watch(self):
         while not self._closed and self._broken is None:
             for rank, proc in enumerate(self.workers, start=1):
@@ -432,18 +459,7 @@ class LeaderEngine:
                     self._broken = f"shard worker {rank} exited with code {code}"
                     self._stop_workers()
                     return
-            # the workers wait for the next frame inside a collective that carries the group's deadline: keep it from expiring
-            if time.time() - self._last_frame > self.timeout_s / 3 and self._lock.acquire(blocking=False):
-                try:
-                    if not self._closed and self._broken is None and time.time() - self._last_frame > self.timeout_s / 3:
-                        self._send(OP_NOP)
-                except BaseException as exc:      # noqa: BLE001
-                    self._broken = f"heartbeat failed: {type(exc).__name__}: {exc}"
-                    self._stop_workers()
-                    return
-                finally:
-                    self._lock.release()
-            time.sleep(min(0.2, self.timeout_s / 10))
+            time.sleep(0.2)
 
     def _stop_workers(self):
         for proc in self.workers:
@@ -474,7 +490,6 @@ class LeaderEngine:
 
     def _send(self, op, *args, **kw):
         self.channel.send(op, *args, **kw)
-        self._last_frame = time.time()
 
     # -- one table operation, in the leader's order -------------------------------------------------------------------
     def run(self, op, table=0, n=0, a=0, b=0, c=0, payload=b""):
@@ -614,6 +629,7 @@ class LeaderEngine:
                     self.engine.close()
                 except BaseException as exc:      # noqa: BLE001 -- closing must not hang on a dead peer
                     self._broken = f"{type(exc).__name__}: {exc}"
+            self.channel.close()                  # (a worker still waiting for a request sees the end of its pipe)
             self._closed = True
             if _LEADER is self:
                 _LEADER = None

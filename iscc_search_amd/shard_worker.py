@@ -31,14 +31,19 @@ def main():
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]),
                             timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
     engine, ctrl = front.build_rank_engine(os.environ.get(front.ENV_FACTORY), same_gpu, timeout_s)
-    channel = front.Channel(dist, ctrl)
+    channel = front.Channel(dist, ctrl, read_fd=int(os.environ[front.ENV_REQUEST_FD]))
     tables = {}
     code = 0
+    trace = os.environ.get("ISCC_HIP_SHARD_TRACE") == "1"      # per-operation wall time of this rank on stderr (tools/probe_leader_search.py)
+    import time
+
     try:
         while True:
+            t_wait = time.perf_counter()
             op, table, n, a, b, c, payload = channel.recv()
+            t_op = time.perf_counter()
             if op == front.OP_NOP:
-                continue                 # the leader's heartbeat: an idle front must not run into the collective deadline
+                continue
             if op == front.OP_SHUTDOWN:
                 break
             error = result = None
@@ -54,6 +59,8 @@ def main():
                     engine.all_reduce(np.array([result], dtype=np.int64))
             elif error is not None:
                 raise error
+            if trace:
+                print(f"[shard worker {os.environ['RANK']}] op {op} n {n}: waited {(t_op - t_wait) * 1e3:.3f} ms, ran {(time.perf_counter() - t_op) * 1e3:.3f} ms", file=sys.stderr)
     except BaseException:                # noqa: BLE001 -- this shard is gone, and says so by exiting
         traceback.print_exc()
         code = 3

@@ -226,6 +226,22 @@ def test_instance_units_match_by_prefix_both_ways(manager, rng):
         assert all(t == {"INSTANCE_NONE_V0": 1.0} for t in got.values())
 
 
+def test_more_instance_matches_than_the_first_short_list(manager, rng):
+    """An INSTANCE match asks for 64 records first; 150 assets sharing a prefix come back through the second, full-length request."""
+    from iscc_search_amd.index import INSTANCE_FIRST_K
+
+    manager.create_index(IsccIndex(name="t"))
+    inst = rng.integers(0, 256, size=8, dtype=np.uint8).tobytes()
+    n = 150
+    assert n > INSTANCE_FIRST_K
+    manager.add_assets("t", [IsccEntry(iscc_id=make_iscc_id(i), units=[rnd_unit(rng, codec.MT_DATA), codec.encode_unit(codec.MT_INSTANCE, 0, 0, inst)]) for i in range(n)]
+                       + [IsccEntry(iscc_id=make_iscc_id(n), units=[rnd_unit(rng, codec.MT_DATA), rnd_unit(rng, codec.MT_INSTANCE)])])
+    res = manager.search_assets("t", IsccQuery(units=[codec.encode_unit(codec.MT_INSTANCE, 0, 0, inst)]), limit=1000)
+    assert {m.iscc_id for m in res.global_matches} == {make_iscc_id(i) for i in range(n)}
+    idx = manager._indexes["t"]
+    assert len(idx._search_instance_unit("INSTANCE_NONE_V0", inst)) == n
+
+
 def test_single_unit_helpers_agree_with_the_batched_path(manager, rng):
     """``_search_similarity_unit`` / ``_search_instance_unit`` (the reference's per-unit methods, usearch/index.py:2024-2045,
     :1957-2022) return what ``_search_units`` (one engine call for all units of a request) merges."""
