@@ -106,6 +106,12 @@ class HipShardOps:
         base = gathered.data_ptr()
         return self.engine.merge_device(n_lists, nq, k, self.key_words, base, base + rec_bytes, blk, blk, after_stream=self._stream())
 
+    def merge_strided(self, gathered, offset, stride, n_lists, nq, k):
+        """The same for a block that is one PART of every rank's share of a fused exchange: list l sits at offset + l x stride."""
+        rec_bytes, _ = block_bytes(nq, k)
+        base = gathered.data_ptr() + offset
+        return self.engine.merge_device(n_lists, nq, k, self.key_words, base, base + rec_bytes, stride, stride, after_stream=self._stream())
+
 
 class ShardedTable:
     """
@@ -224,6 +230,52 @@ class ShardedTable:
             cnt = out[3]
             full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
             state[0] = int(out[1][:, k - 1].max()) + 2 if full else None       # (a table with fewer than k rows never gets a hint)
+        return out
+
+    @staticmethod
+    def search_many(items):
+        """
+        Several searches -- the per-unit searches of one ``search_assets`` request (``usearch/index.py:786-806``), each on its own
+        table -- with ONE exchange: every shard runs its local searches back to back, their blocks travel in one all-gather, each
+        part is merged on its own.  ``items`` = [(ShardedTable, q_words, q_nbytes, k, max_hamming | None)], queries of one length
+        per item; returns the results in order, or None when the items cannot share an exchange (the caller then runs them one
+        by one).  No threshold hints here: these are single queries, whose local searches speculate on their own.
+        """
+        import torch
+
+        first = items[0][0]
+        if first.world_size == 1 or len(items) < 2 or len({(id(t.ops), q.shape[0], k) for t, q, _, k, _ in items}) != len(items):
+            return None            # (two items on one table with one block size would share that table's block buffer)
+        if any(t.world_size != first.world_size or t.group is not first.group for t, *_ in items):
+            return None
+        blocks = []
+        for t, q_words, q_nbytes, k, max_hamming in items:
+            blocks.append(t.ops.local_search(q_words, q_nbytes, k) if max_hamming is None else t.ops.local_search(q_words, q_nbytes, k, max_hamming))
+        share = torch.cat(blocks)
+        total = share.numel()
+        if share.is_cuda and first.dist.get_backend(first.group) == "gloo":
+            host = torch.empty(first.world_size * total, dtype=share.dtype)      # rehearsal transport: staged through the host
+            first.dist.all_gather_into_tensor(host, share.cpu(), group=first.group)
+            gathered = host.to(share.device)
+        else:
+            make = getattr(first.ops, "buffer", None)
+            gathered = make("gathered", first.world_size * total) if make else torch.empty(first.world_size * total, dtype=share.dtype, device=share.device)
+            first.dist.all_gather_into_tensor(gathered, share, group=first.group)
+        out, offset = [], 0
+        for (t, q_words, q_nbytes, k, max_hamming), block in zip(items, blocks):
+            nq = q_words.shape[0]
+            strided = getattr(t.ops, "merge_strided", None)
+            if strided is not None:
+                res = strided(gathered, offset, total, t.world_size, nq, k)
+            else:
+                part = gathered.view(t.world_size, total)[:, offset : offset + block.numel()].contiguous().view(-1)
+                res = t.ops.merge(part, t.world_size, nq, k)
+            if np.any(res[3] == COUNT_OVERFLOW):
+                # a shard could only mark an overflowed candidate list: the merged counts are the same on every rank, so every rank
+                # repeats THIS item through the synchronous path together
+                res = t._exchange(q_words, q_nbytes, k, max_hamming, {"synchronous": True})
+            out.append(res)
+            offset += block.numel()
         return out
 
     def _exchange(self, q_words, q_nbytes, k, max_hamming, how):

@@ -107,11 +107,24 @@ class ShardedEngine:
 
     def search_many(self, requests):
         # type: (list[tuple]) -> list[tuple]
-        """The per-unit searches of one ``search_assets`` request; each is one local search + all-gather + merge."""
-        out = []
+        """
+        The per-unit searches of one ``search_assets`` request: local searches back to back, ONE all-gather for all of them, one
+        merge each (``ShardedTable.search_many``); requests that cannot share an exchange (queries of several lengths in one
+        request, two requests on one table) run one by one.
+        """
+        items = []
         for table, q_words, q_nbytes, k, max_hamming in requests:
             if k < 1:
                 raise ValueError("`count` must be >= 1")
+            q_words = np.ascontiguousarray(q_words, dtype=np.uint64).reshape(-1, table.max_words)
+            q_nbytes = None if q_nbytes is None else np.ascontiguousarray(q_nbytes, dtype=np.uint8)
+            items.append((table._sharded, q_words, q_nbytes, k, None if max_hamming is None else int(max_hamming)))
+        if all(qn is None or len(np.unique(qn)) <= 1 for _, _, qn, _, _ in items) and all(q.shape[0] for _, q, _, _, _ in items):
+            fused = ShardedTable.search_many(items)
+            if fused is not None:
+                return fused
+        out = []
+        for table, q_words, q_nbytes, k, max_hamming in requests:
             out.append(table.search(q_words, q_nbytes, k) if max_hamming is None else table.search_within(q_words, q_nbytes, k, max_hamming))
         return out
 
