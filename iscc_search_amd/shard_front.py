@@ -179,7 +179,7 @@ def run_table_op(engine, tables, op, table_id, n, a, b, c, payload):
         engine.set_option(payload.decode(), n)
         return None
     if op == OP_SEARCH_MANY:
-        out, off = [], 0
+        requests, off = [], 0
         for _ in range(n):
             tid, nq, k, radius, has_len = (int(x) for x in np.frombuffer(payload, dtype=np.int64, count=5, offset=off))
             off += 40
@@ -190,8 +190,8 @@ def run_table_op(engine, tables, op, table_id, n, a, b, c, payload):
             if has_len:
                 qn = np.frombuffer(payload, dtype=np.uint8, count=nq, offset=off)
                 off += (nq + 7) // 8 * 8
-            out.append(t.search(qw, qn, k) if radius == NO_RADIUS else t.search_within(qw, qn, k, radius))
-        return out
+            requests.append((t, qw, qn, k, None if radius == NO_RADIUS else radius))
+        return engine.search_many(requests)       # local searches back to back, ONE all-gather, one merge each
     t = tables[table_id]
     kw, mw = t.key_words, t.max_words
     if op == OP_DROP:

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Where a search_assets call through the leader front spends its time (cProfile of the leader; two ranks on one GPU)."""
-import cProfile
+"""Where a search_assets call through the leader front spends its time on the leader (two ranks on one GPU): phase timers."""
+import collections
 import os
-import pstats
 import sys
 import time
 
@@ -12,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from bench_protocol import make_asset  # noqa: E402
+from iscc_search_amd import shard_front, sharded  # noqa: E402
 from iscc_search_amd.index import HipIndexManager  # noqa: E402
 from iscc_search_amd.schema import IsccIndex, IsccQuery  # noqa: E402
 
@@ -21,35 +21,41 @@ assets = [make_asset(rng, i) for i in range(2500)]
 m = HipIndexManager(uri)
 m.create_index(IsccIndex(name="c1"))
 m.add_assets("c1", assets)
-for label, pick in (("META only", lambda a: a.units[:1]), ("META+CONTENT+DATA", lambda a: a.units[:3]), ("INSTANCE only", lambda a: a.units[3:]), ("all four", lambda a: a.units)):
-    qs = [IsccQuery(units=pick(a)) for a in assets[:30]]
+acc = collections.defaultdict(float)
+
+
+def wrap(obj, name, label):
+    inner = getattr(obj, name)
+
+    def timed(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return inner(*a, **k)
+        finally:
+            acc[label] += time.perf_counter() - t0
+
+    setattr(obj, name, timed)
+
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+wrap(sharded.HipShardOps, "local_search", "local_search (async enqueue)")
+wrap(sharded.HipShardOps, "merge_strided", "merge_strided (launch + sync + unpack)")
+wrap(sharded.HipShardOps, "merge", "merge (launch + sync + unpack)")
+wrap(dist, "all_gather_into_tensor", "all_gather_into_tensor")
+wrap(torch, "cat", "torch.cat")
+wrap(shard_front.Channel, "send", "request pipe write")
+wrap(shard_front.LeaderEngine, "run", "LeaderEngine.run (whole operation)")
+for label, pick in (("1 unit", lambda a: a.units[:1]), ("4 units", lambda a: a.units)):
+    qs = [IsccQuery(units=pick(a)) for a in assets[:100]]
     m.search_assets("c1", qs[0], limit=10)
+    acc.clear()
     t0 = time.perf_counter()
     for q in qs:
         m.search_assets("c1", q, limit=10)
-    print(f"{label}: {(time.perf_counter() - t0) / len(qs) * 1e3:.3f} ms per search_assets")
-os.environ["ISCC_PROBE_PHASES"] = "1"
-from iscc_search_amd import sharded  # noqa: E402
-
-orig = sharded.ShardedTable._exchange
-
-
-def timed_exchange(self, q_words, q_nbytes, k, max_hamming, how):
-    t0 = time.perf_counter()
-    out = orig(self, q_words, q_nbytes, k, max_hamming, how)
-    print(f"[leader] exchange nq {q_words.shape[0]} k {k} radius {max_hamming}: {(time.perf_counter() - t0) * 1e3:.3f} ms")
-    return out
-
-
-sharded.ShardedTable._exchange = timed_exchange
-for a in assets[:3]:
-    m.search_assets("c1", IsccQuery(units=a.units), limit=10)
-sharded.ShardedTable._exchange = orig
-qs = [IsccQuery(units=a.units[:1]) for a in assets[:10]]
-pr = cProfile.Profile()
-pr.enable()
-for q in qs:
-    m.search_assets("c1", q, limit=10)
-pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+    total = (time.perf_counter() - t0) / len(qs)
+    print(f"{label}: {total * 1e3:.3f} ms per search_assets")
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+        print(f"    {k:45s} {v / len(qs) * 1e6:8.1f} us")
 m.close()
