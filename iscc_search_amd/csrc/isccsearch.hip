@@ -2491,6 +2491,14 @@ int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_
     if (max_hamming > 256) return fail(-EINVAL, "max_hamming %d exceeds 256", max_hamming);
     const int radius = max_hamming < 0 ? -1 : max_hamming;
     bool async = nq > 0 && nq <= QB_MAX && k >= 1 && k <= ISCCSEARCH_MAX_K && q_words && d_records && d_counts;
+    // the one-shot hint belongs to THIS call whatever becomes of it: read and clear it before anything can return (an early
+    // return used to leave it armed for the next, unrelated call, whose caller would not verify its lists)
+    int hint;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        hint = h->device_search_hint;
+        h->device_search_hint = -1;
+    }
     if (async) {
         std::lock_guard<std::mutex> lk(h->mu);
         Table* tp;
@@ -2514,8 +2522,7 @@ int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_
             batch.mark_overflow = true;
             // (sharded callers: the GLOBAL k-th distance of the previous step + margin -- every shard then lists its rows under it,
             //  tightening as it finds k of its own, and the caller accepts the merged lists only if they hold k rows per query)
-            if (radius < 0 && h->device_search_hint >= 0) batch.self_hint = h->device_search_hint;
-            h->device_search_hint = -1;
+            if (radius < 0 && hint >= 0) batch.self_hint = hint;
             if ((rc = batch.begin(q_words))) return rc;
             HIPOK(hipEventRecord(h->ev_done, h->stream));
             HIPOK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->ev_done, 0));
@@ -2524,7 +2531,6 @@ int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_
     }
     // several segments (their lists must be fixed and merged with the host's help), oversized batches, bad arguments: the
     // synchronous path does the work and the reporting; the results are complete when it returns
-    h->device_search_hint = -1;
     return search_device_impl(h, table, nq, q_words, q_nbytes, k, radius, d_records, d_counts);
 }
 
