@@ -102,6 +102,9 @@ typedef struct isccsearch_stats {
     /* small batches answered by ONE speculative range-limited pass under the previous search's k-th distance / sent on to the
        ordinary path because a query found fewer than k rows within it (or a list overflowed) */
     uint64_t spec_hits, spec_misses;
+    /* while profiling: candidate-list entries the scan launches appended (summed over queries; the lists of the LAST pipeline run of
+       every batch, read back after its synchronisation), and the batches they were counted over */
+    uint64_t candidates, candidate_batches;
 } isccsearch_stats;
 
 /* Engine lifetime.  One handle drives one GPU (one process per GPU). */

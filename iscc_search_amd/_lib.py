@@ -69,6 +69,8 @@ class Stats(ctypes.Structure):
         ("mfma_pack_launches", ctypes.c_uint64),
         ("spec_hits", ctypes.c_uint64),
         ("spec_misses", ctypes.c_uint64),
+        ("candidates", ctypes.c_uint64),
+        ("candidate_batches", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -93,9 +93,14 @@ struct Segment {
             if (skip) { skip -= 1; return false; }
             return true;
         }
-        void hit(uint32_t worst) { penalty = 0; tau = std::min<uint32_t>(std::max<uint32_t>(worst + 2, tau ? tau - 1 : 0), 8 * ISCCSEARCH_MAX_BYTES); }
+        // margin above the worst k-th distance the last batch ended at.  The k-th distance of a query concentrates as k grows (it is an
+        // order statistic k deep into the distribution), and so does its maximum over a batch: from k = 64 one bit is enough -- and a bit
+        // is worth a factor ~2.6 in candidates at these distances (10 M x 64-bit, 512 queries, k = 400: 3 480 candidates per query
+        // under + 2, profiles/r04_candidate_path.txt).  Small k keeps two: its k-th distance wanders more and a bit costs little there.
+        static uint32_t margin(uint32_t want_k) { return want_k >= 64 ? 1u : 2u; }
+        void hit(uint32_t worst) { penalty = 0; tau = std::min<uint32_t>(std::max<uint32_t>(worst + margin(k), tau ? tau - 1 : 0), 8 * ISCCSEARCH_MAX_BYTES); }
         void miss() { penalty = std::min<uint32_t>(2 * penalty + 1, 15); skip = penalty - 1; }      // (the rerun that follows is the first skipped batch)
-        void seed(uint32_t new_k, uint32_t worst) { k = new_k; tau = std::min<uint32_t>(worst + 2, 8 * ISCCSEARCH_MAX_BYTES); }
+        void seed(uint32_t new_k, uint32_t worst) { k = new_k; tau = std::min<uint32_t>(worst + margin(new_k), 8 * ISCCSEARCH_MAX_BYTES); }
     } spec[12][5];
     // one hint per batch-size class (1 | 2-3 | 4-7 | ... | 1024) and per compared PREFIX length (8 / 16 / 24 / 32 bytes and the odd ones:
     // an NPHD table of 256-bit rows answers 64-bit queries over a 64-bit prefix, whose k-th distance has nothing to do with a 256-bit one's)
@@ -622,7 +627,10 @@ struct Batch {
         // the self-tightening pass never prunes: ~17 k entries per query over 100 M rows (+ the flood of the first steps)
         if (h->self_tighten && h->mfma && k <= h->self_max_k && radius < 0 && radius_ratio < 0) cap = std::max<uint32_t>(cap, 64 * k);
         multi = jobs.size() > 1;
-        P = next_pow2(std::max<uint32_t>(k, 1024));   // select's LDS sort buffer: room for small tie classes (12-20 KB)
+        // select's LDS sort buffer: room for the k winners AND the tie class at the cut -- with 65 distinct distances the class is
+        // ~1.5-2.5 k rows at simprint-sized k, and a list that does not fit takes up to 8 / 16 radix passes over its gathered keys first
+        // (10 M x 64-bit, 512 queries, k = 400: 154 us per select with 1 024 slots; profiles/r04_candidate_path.txt)
+        P = next_pow2(std::max<uint32_t>(std::max<uint32_t>(k, 1024), std::min<uint32_t>(4 * k, 4096)));
         sel_lds = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 8 * t.key_words + (d_out_rows ? (size_t)P * 4 : 0);
         int rc;
         if ((rc = h->d_queries.ensure((size_t)nq_pad * 4))) return rc;
@@ -1910,6 +1918,14 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                     if ((rc = finish())) return rc;
                 }
             } else if ((rc = finish())) return rc;
+        }
+        if (h->profile && batch.jobs.size() == 1) {
+            // accounting (tools/probe_candidate_path.py): how many candidates the scan appended for this batch
+            std::vector<uint32_t> hc((size_t)batch.nq_pad * isk::CNT_STRIDE);
+            HIPOK(hipMemcpyAsync(hc.data(), h->d_cnt.p, hc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPOK(hipStreamSynchronize(h->stream));
+            for (uint32_t i = 0; i < m; ++i) h->stats.candidates += hc[(size_t)i * isk::CNT_STRIDE];
+            h->stats.candidate_batches += 1;
         }
         if (hintable && !batch.jobs.empty()) {
             // where this batch's lists ended: the next small batch of this segment starts there (+ 2: P(h <= t) grows ~3x per

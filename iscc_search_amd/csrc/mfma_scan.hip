@@ -60,6 +60,9 @@ template <int W> constexpr int mfma_tiles() { return W == 4 ? ISK_MFMA_TILES_W4 
 // MFMAs per 17 fold instructions the matrix pipe, not the issue order, is the bound there.  Off.
 #define ISK_ORDERED_STAGE 0
 #endif
+#ifndef ISK_EXP_NO_CANDIDATE_MEMORY
+#define ISK_EXP_NO_CANDIDATE_MEMORY 0     // experiment switch (never in the product build): candidates are found but not appended
+#endif
 #ifndef ISK_SCALAR_STEPS_FROM_W
 #define ISK_SCALAR_STEPS_FROM_W 2     // experiment switch: code widths (in 64-bit words) from which the step number is kept scalar
 #endif
@@ -663,6 +666,11 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
             // (d < -64 is no dot product of 64 bits: never turned into an index)
             if (below && d >= -64 && row <= last_row) {
                 const int pc = lpop[ql];
+#if ISK_EXP_NO_CANDIDATE_MEMORY
+                // EXPERIMENT (results are wrong): what does the candidate path cost WITHOUT its global memory operations?
+                asm volatile("" ::"v"(pc), "v"(d), "v"(row));
+                continue;
+#endif
                 if constexpr (MODE == MODE_SELF) {
                     pend_complete();
                     const uint32_t qi = q0 + ql, hd = (uint32_t)(d + pc);

@@ -36,6 +36,12 @@ def shard_of_key(key_lo, world_size):
     return (x >> 32) % world_size
 
 
+def hint_margin(k):
+    # type: (int) -> int
+    """Bits above the previous step's worst k-th distance a hinted step starts at: as the engine's own hints (isccsearch.hip, SpecHint::margin)."""
+    return 1 if k >= 64 else 2
+
+
 def block_bytes(nq, k):
     # type: (int, int) -> tuple[int, int]
     """Per-rank exchange block {records [nq][k] | counts [nq] | pad}: (record bytes, block bytes)."""
@@ -213,7 +219,7 @@ class ShardedTable:
                 cnt = out[3]
                 if not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k:
                     worst = int(out[1][:, k - 1].max())
-                    state[0], state[2] = max(worst + 2, state[0] - 1), 0          # decays by one bit per step towards what the batches need
+                    state[0], state[2] = max(worst + hint_margin(k), state[0] - 1), 0          # decays by one bit per step towards what the batches need
                     self.hint_hits += 1
                     return out
                 self.hint_misses += 1
@@ -229,7 +235,7 @@ class ShardedTable:
         if state is not None:
             cnt = out[3]
             full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
-            state[0] = int(out[1][:, k - 1].max()) + 2 if full else None       # (a table with fewer than k rows never gets a hint)
+            state[0] = int(out[1][:, k - 1].max()) + hint_margin(k) if full else None       # (a table with fewer than k rows never gets a hint)
         return out
 
     @staticmethod
