@@ -83,12 +83,16 @@ def test_search_exact_edges(engine):
     assert res[0].matches == 2 and res[0].queried == 2 and res[0].score == 0.5 and len(res[0].chunks) == 2
 
 
-def test_search_exact_random_against_python_model(engine):
-    """Many collisions, 128-bit simprints: compare with a dict-based model of the LMDB dupsort walk."""
+@pytest.mark.parametrize("n_rows,pool_size,dup_limit", [(600, 12, 25), (900, 3, 200)])
+def test_search_exact_random_against_python_model(engine, n_rows, pool_size, dup_limit):
+    """
+    Many collisions, 128-bit simprints: compare with a dict-based model of the LMDB dupsort walk.  The second shape has ~300
+    collisions per simprint and dup_limit 200: lookups whose first short list (EXACT_FIRST_K = 64) comes back full are repeated.
+    """
     rng = np.random.default_rng(11)
-    pool = [rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for _ in range(12)]
+    pool = [rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for _ in range(pool_size)]
     rows, seen = [], set()
-    while len(rows) < 600:
+    while len(rows) < n_rows:
         body = int(rng.integers(1, 40)).to_bytes(8, "big")
         off, size = int(rng.integers(0, 50)) * 10, int(rng.integers(1, 5)) * 100
         if (body, off, size) in seen:
@@ -96,8 +100,7 @@ def test_search_exact_random_against_python_model(engine):
         seen.add((body, off, size))
         rows.append([pool[int(rng.integers(0, len(pool)))].hex(), body.hex(), off, size])
     idx = _fill(engine, rows, ndim=128)
-    query = [pool[0], pool[3], pool[3], pool[7], rng.integers(0, 256, 16, dtype=np.uint8).tobytes()]
-    dup_limit = 25
+    query = [pool[0], pool[3 % pool_size], pool[3 % pool_size], pool[7 % pool_size], rng.integers(0, 256, 16, dtype=np.uint8).tobytes()]
     by_sp = {}
     for spx, body, off, size in rows:
         by_sp.setdefault(bytes.fromhex(spx), []).append(pack_chunk_pointer(bytes.fromhex(body), off, size))
