@@ -102,7 +102,7 @@ typedef struct isccsearch_stats {
     /* small batches answered by ONE speculative range-limited pass under the previous search's k-th distance / sent on to the
        ordinary path because a query found fewer than k rows within it (or a list overflowed) */
     uint64_t spec_hits, spec_misses;
-    /* while profiling: candidate-list entries the scan launches appended (summed over queries; the lists of the LAST pipeline run of
+    /* with option "count_candidates" = 1: candidate-list entries the scan launches appended (summed over queries; the lists of the LAST pipeline run of
        every batch, read back after its synchronisation), and the batches they were counted over */
     uint64_t candidates, candidate_batches;
 } isccsearch_stats;
@@ -131,7 +131,9 @@ const char* isccsearch_last_error(void);
  * caches instead of HBM; default 128, 0 = one streaming pass per group; matrix-core launches whose query chunks share the rows take
  * "mfma_stretch_factor" (3) times that), "fold_tau" (whole 64-bit codes: query groups whose
  * thresholds are all <= this take the folded 3.5-op fast path; default 11, 0 = never); tuning: "blocks_per_cu", "boot_rows",
- * "level_growth", "repick".  "nontemporal" accepts only 1 (the only variant built). */
+ * "level_growth", "repick"; "count_candidates" (0|1: after every batch read back how many candidates its scan appended --
+ * statistics `candidates` / `candidate_batches`; one more copy and synchronisation per batch, for accounting runs).
+ * "nontemporal" accepts only 1 (the only variant built). */
 int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);
 int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset);
 

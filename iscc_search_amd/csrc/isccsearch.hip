@@ -196,6 +196,7 @@ struct isccsearch_handle {
     // options
     int tq = 8;   // queries per streaming pass: 8 keeps the scan HBM-bound
     bool profile = false;
+    bool count_candidates = false;   // read the candidate counters back after every batch (one more copy + synchronisation: accounting runs only)
     bool nontemporal = true;
     uint32_t blocks_per_cu = 8;    // scan grid = CUs x this (per query group)
     uint64_t boot_rows = 65536;    // rows of the threshold bootstrap of the level design (4 096 exact + the rest counted under that
@@ -1195,6 +1196,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
         return 0;
     }
     if (!strcmp(name, "profile")) { h->profile = value != 0; return 0; }
+    if (!strcmp(name, "count_candidates")) { h->count_candidates = value != 0; return 0; }
     if (!strcmp(name, "nontemporal")) {
         // only the non-temporal variant of the scan kernels is built (plain loads measured no faster):
         // asking for the other one is refused rather than silently ignored
@@ -1919,8 +1921,8 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 }
             } else if ((rc = finish())) return rc;
         }
-        if (h->profile && batch.jobs.size() == 1) {
-            // accounting (tools/probe_candidate_path.py): how many candidates the scan appended for this batch
+        if (h->count_candidates && batch.jobs.size() == 1) {
+            // accounting (tools/probe_candidate_path.py, option "count_candidates"): how many candidates the scan appended for this batch
             std::vector<uint32_t> hc((size_t)batch.nq_pad * isk::CNT_STRIDE);
             HIPOK(hipMemcpyAsync(hc.data(), h->d_cnt.p, hc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
             HIPOK(hipStreamSynchronize(h->stream));

@@ -48,11 +48,13 @@ def main():
                 fn()
             engine.stats(reset=True)
             engine.set_option("profile", 1)
+            engine.set_option("count_candidates", 1)
             t0 = time.perf_counter()
             for _ in range(reps):
                 out = fn()
             wall = (time.perf_counter() - t0) / reps
             engine.set_option("profile", 0)
+            engine.set_option("count_candidates", 0)
             st = engine.stats(reset=True)
             launches = st["scan_launches"] + st["level_launches"]
             return {"scan_ms": (st["scan_ms"] + st["level_ms"]) / reps, "launches": launches / reps, "wall_ms": wall * 1e3,
