@@ -1105,7 +1105,14 @@ uint32_t mfma_groups_per_chunk(int W, uint32_t nq_pad, bool pack) {
     if (pack) return need < 1 ? 1 : (need < max_groups[1] ? need : max_groups[1]);      // mfma_pack_kernel takes any number of groups
     need += need & 1;                         // the pipeline of mfma_scan_kernel walks the groups in pairs
     if (need < 2) need = 2;
-    return need < max_groups[W] ? need : max_groups[W];
+    if (need <= max_groups[W]) return need;
+    // several chunks: as many as the LDS limit asks for, each as SMALL as that number of chunks allows -- 1 024 queries of 192-bit
+    // codes are 32 groups: four chunks of 10 multiplied 40 groups' worth (a fifth of the MFMAs on padding queries: the matrix pipe
+    // 0.75 busy for 0.53 of the peak, profiles/r04_pmc_sq_widths.txt), four chunks of 8 multiply 32
+    const uint32_t chunks = (need + max_groups[W] - 1) / max_groups[W];
+    uint32_t g = (need + chunks - 1) / chunks;
+    g += g & 1;
+    return g < max_groups[W] ? g : max_groups[W];
 }
 
 // B fragments | thresholds | popcounts | the four waves' rings of saved result blocks
