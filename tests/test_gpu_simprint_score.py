@@ -207,3 +207,93 @@ def test_ten_million_chunks(engine):
     for r, w in zip(got, want):
         assert [(c.query, c.match, c.score, c.offset, c.size, c.freq) for c in r.chunks] == [(simprints[qi], m, s, o, z, f) for qi, m, s, o, z, f in w[3]]
     index.close()
+
+
+def test_scores_follow_additions_and_removals(engine):
+    """
+    Differential run over a changing table: chunks are added and removed between requests (the frequency column is dropped by
+    every change and rebuilt by the next request); after every change the device's answer must equal the checker's over the
+    oracle-backed twin.
+    """
+    rng = np.random.default_rng(4242)
+    ndim = 128
+    pool = [rng.integers(0, 256, size=ndim // 8, dtype=np.uint8).tobytes() for _ in range(25)]
+    index, oracle = HipSimprintIndex(engine, ndim=ndim), HipSimprintIndex(OracleEngine(), ndim=ndim)
+    live = {}                                   # chunk pointer -> simprint bytes
+    next_asset = [1]
+
+    def add(n_assets):
+        keys, vecs = [], []
+        for _ in range(n_assets):
+            body = next_asset[0].to_bytes(8, "big")
+            next_asset[0] += 1
+            for c in range(int(rng.integers(1, 7))):
+                v = flip_bits(pool[int(rng.integers(0, len(pool)))], int(rng.integers(0, 9)))
+                k = pack_chunk_pointer(body, c * 16, 16)
+                keys.append(k)
+                vecs.append(np.frombuffer(v, dtype=np.uint8))
+                live[k] = v
+        index.add_raw(keys, vecs)
+        oracle.add_raw(keys, vecs)
+
+    def remove(n):
+        victims = [list(live)[int(i)] for i in rng.choice(len(live), size=min(n, len(live)), replace=False)]
+        for k in victims:
+            del live[k]
+        index.remove(victims)
+        oracle.remove(victims)
+
+    add(120)
+    for round_ in range(12):
+        if round_ % 3 == 2:
+            remove(int(rng.integers(5, 60)))
+        else:
+            add(int(rng.integers(5, 40)))
+        simprints = [flip_bits(pool[int(rng.integers(0, len(pool)))], int(rng.integers(0, 5))) for _ in range(int(rng.integers(1, 30)))]
+        assets = len({k[:8] for k in live})
+        _check(index, oracle, simprints, int(rng.integers(1, 15)), float(rng.choice([0.0, 0.8, 0.9, 0.95])), assets, device_doc_freq=bool(round_ % 2))
+        assert index.size == len(live)
+    index.close()
+
+
+def test_concurrent_requests_and_writers(engine):
+    """Scoring calls from several threads beside a writer: every call is serialised by the handle and answers a consistent table."""
+    import threading
+
+    rng = np.random.default_rng(99)
+    pool, keys, vecs = _corpus(rng, 64, assets=200, chunks_per_asset=4, pool_size=20, max_flip=3)
+    index = HipSimprintIndex(engine, ndim=64)
+    index.add_raw(keys, vecs)
+    simprints = [flip_bits(p, 1) for p in pool]
+    want = index.search_raw(simprints, limit=10, threshold=0.8, detailed=True, total_assets=200, device_doc_freq=True)
+    errors, stop = [], threading.Event()
+
+    def reader():
+        try:
+            while not stop.is_set():
+                got = index.search_raw(simprints, limit=10, threshold=0.8, detailed=True, total_assets=200, device_doc_freq=True)
+                if [(r.iscc_id_body, r.score) for r in got] != [(r.iscc_id_body, r.score) for r in want]:
+                    errors.append("a reader saw another answer")
+                    return
+        except BaseException as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def writer():
+        # far from every query (all-ones / all-zero codes of assets beyond the corpus): the answer must not change
+        try:
+            for i in range(30):
+                k = [pack_chunk_pointer((10_000 + i).to_bytes(8, "big"), j, 1) for j in range(3)]
+                index.add_raw(k, [np.frombuffer(bytes([0xFF * (j & 1)] * 8), dtype=np.uint8) for j in range(3)])
+                index.remove(k[:2])
+        except BaseException as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=reader) for _ in range(4)] + [threading.Thread(target=writer)]
+    for t in threads:
+        t.start()
+    threads[-1].join()
+    stop.set()
+    for t in threads[:-1]:
+        t.join()
+    assert errors == []
+    index.close()
