@@ -270,6 +270,21 @@ int isccsearch_simprint_score(isccsearch_handle* h, uint32_t table, uint32_t nq,
                               isccsearch_simprint_result* out_results, isccsearch_simprint_chunk* out_chunks,
                               uint64_t* out_chunk_words, uint32_t* out_info);
 
+/* Hard-boundary simprint search WITH its scoring, on the device: search_simprints_exact (iscc_search/indexes/simprint/lmdb_ops.py:169-301,
+ * called with exact=True from iscc_search/indexes/usearch/index.py:1261-1304).  q_words[n_distinct * max_words] are the DISTINCT query
+ * simprints; given[n_given] names, for every query simprint of valid length AS GIVEN (repeats included: a repeated simprint is matched
+ * again, :197), its index among the distinct ones; `queried` = the number of query simprints the caller was given (the denominator
+ * of the coverage, :286).  Per distinct simprint every stored row EQUAL to it is listed in ascending key order, at most dup_limit
+ * (:199-210; capped at ISCCSEARCH_MAX_K); on those lists, in device memory: document frequencies (distinct assets per list, :213-215),
+ * the matches of every asset in visiting order, coverage x quality (:252-301) with the reference's float64 operations in the
+ * reference's order, the threshold (:222-223), order (-score, asset) and the cut to `limit` (:247-248).
+ * out_results[limit]; out_chunks (nullable) [sum of list lengths over the given simprints]: chunks of result r are out_chunks[first_chunk
+ * .. first_chunk + matches), in visiting order -- `query` = position in given[], hamming 0, freq = the simprint's document frequency;
+ * out_info[4] = {results written, assets kept, longest collision list, chunks written}.  128-bit-key Hamming tables only. */
+int isccsearch_simprint_exact(isccsearch_handle* h, uint32_t table, uint32_t n_distinct, const uint64_t* q_words,
+                              uint32_t n_given, const uint32_t* given, uint32_t queried, uint32_t dup_limit, double threshold, uint32_t limit,
+                              isccsearch_simprint_result* out_results, isccsearch_simprint_chunk* out_chunks, uint32_t* out_info);
+
 /* Multi-GPU building blocks (row-range shards, one process per GPU).
  * search_device: same search, results left in caller-provided DEVICE memory
  *   d_records[nq*k] (isccsearch_record), d_counts[nq]; queries must share one byte length.

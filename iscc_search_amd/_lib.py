@@ -29,7 +29,7 @@ EXPORTS = (
     "isccsearch_size", "isccsearch_add", "isccsearch_remove", "isccsearch_contains", "isccsearch_get",
     "isccsearch_segments", "isccsearch_export", "isccsearch_add_columns",
     "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_search_many", "isccsearch_doc_freq", "isccsearch_doc_freq_counted", "isccsearch_get_freq",
-    "isccsearch_simprint_score",
+    "isccsearch_simprint_score", "isccsearch_simprint_exact",
     "isccsearch_search_device", "isccsearch_search_within_device", "isccsearch_merge_device",
     "isccsearch_search_device_async", "isccsearch_merge_device_after",
 )
@@ -156,6 +156,7 @@ def load_library():
         "isccsearch_doc_freq_counted": (i, [vp, u32, u32, u64p, u8p, u32, u32p, u32p]),
         "isccsearch_get_freq": (i, [vp, u32, u64, u64p, u32, u32p]),
         "isccsearch_simprint_score": (i, [vp, u32, u32, u64p, u32, ctypes.c_int32, ctypes.c_double, u32, ctypes.c_int64, u32, vp, vp, vp, u32p]),
+        "isccsearch_simprint_exact": (i, [vp, u32, u32, u64p, u32, u32p, u32, u32, ctypes.c_double, u32, vp, vp, u32p]),
         "isccsearch_search_device": (i, [vp, u32, u32, u64p, u8p, u32, vp, vp]),
         "isccsearch_search_within_device": (i, [vp, u32, u32, u64p, u8p, u32, u32, vp, vp]),
         "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, u64p, u32p, u16p, u32p]),

@@ -253,6 +253,7 @@ struct isccsearch_handle {
     // isccsearch_simprint_score: the neighbour lists of one request stay on the device with their rows; simprint_score.hip's buffers
     DevBuf<isk::Record> d_sp_rec;
     DevBuf<uint32_t> d_sp_rows, d_sp_nbest, d_sp_offs, d_sp_freqq, d_sp_unknown, d_sp_entry[2], d_sp_order[2], d_sp_matches, d_sp_nassets;
+    DevBuf<uint32_t> d_sp_cnt, d_sp_dofg;       // isccsearch_simprint_exact: list lengths of every lookup, the lookup of every given simprint
     DevBuf<unsigned char> d_sp_best, d_sp_temp;
     DevBuf<uint64_t> d_sp_asset[2];
     DevBuf<double> d_sp_score[2], d_sp_tab, d_sp_ws, d_sp_idfq;
@@ -1174,6 +1175,7 @@ int isccsearch_destroy(isccsearch_handle* h) {
         h->d_block.release(); h->p_block.release();
         h->d_sp_rec.release(); h->d_sp_rows.release(); h->d_sp_nbest.release(); h->d_sp_offs.release(); h->d_sp_freqq.release();
         h->d_sp_unknown.release(); h->d_sp_matches.release(); h->d_sp_nassets.release(); h->d_sp_best.release(); h->d_sp_temp.release();
+        h->d_sp_cnt.release(); h->d_sp_dofg.release();
         for (int i = 0; i < 2; ++i) { h->d_sp_entry[i].release(); h->d_sp_order[i].release(); h->d_sp_asset[i].release(); h->d_sp_score[i].release(); }
         h->d_sp_tab.release(); h->p_sp_tab.release(); h->p_sp_out.release(); h->d_sp_ws.release(); h->d_sp_idfq.release();
         if (h->d_rank) (void)hipFree(h->d_rank);
@@ -1682,6 +1684,7 @@ struct ScoreSink {
     uint32_t entries = 0;       // best (asset, query) entries appended so far -- known after each batch's synchronisation
     uint32_t max_count = 0;     // longest neighbour list
     bool unknown_any = false;   // some query's own document frequency could not be read off its list
+    bool exact = false;         // isccsearch_simprint_exact: the lists are collision lists; only their lengths are kept per batch (no marking)
 };
 
 // The search itself; h->mu is held by the caller.
@@ -1741,7 +1744,7 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         uint32_t* const p_kth = p_cnt + m + flag_slots;                  // (sink) hamming of every query's last result
         Batch batch(h, t, m, len, k, d_rec, d_cnt);
         batch.radius = radius;
-        if (sink) { batch.d_out_rows = h->d_sp_rows.p + (size_t)pos * k; batch.d_out_kth = d_cnt + m + flag_slots; }
+        if (sink) { if (!sink->exact) batch.d_out_rows = h->d_sp_rows.p + (size_t)pos * k; batch.d_out_kth = d_cnt + m + flag_slots; }
         if (one_copy) { batch.d_flags = d_cnt + m; batch.h_flags = p_cnt + m; }
         // (see the speculative branch below) eligible: an ordinary top-k search of a small batch over ONE segment that has been
         // searched with this k before
@@ -1775,8 +1778,12 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 // the lists are final on the device (or will be redone and this queued again): mark the best chunk of every
                 // (asset, query), append them to the request's entry list; the host gets counts, flags, k-th distances and info
                 uint32_t* const d_info = d_cnt + m + flag_slots + m;
-                isksp::BatchArgs ba{pos, m, k, d_cnt, sink->h_max, sink->dup_limit, sink->entries, d_info};
-                HIPOK(isksp::queue_batch(sink->buf, ba, h->stream));
+                if (sink->exact) {
+                    HIPOK(hipMemcpyAsync(h->d_sp_cnt.p + pos, d_cnt, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+                } else {
+                    isksp::BatchArgs ba{pos, m, k, d_cnt, sink->h_max, sink->dup_limit, sink->entries, d_info};
+                    HIPOK(isksp::queue_batch(sink->buf, ba, h->stream));
+                }
                 HIPOK(hipMemcpyAsync(h->p_block.p, h->d_block.p, block_bytes, hipMemcpyDeviceToHost, h->stream));
                 return 0;
             }
@@ -1941,8 +1948,10 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         if (sink) {
             if (!batch.jobs.empty()) {
                 const uint32_t* p_info = p_kth + m;
-                sink->entries = p_info[0];
-                sink->unknown_any = sink->unknown_any || p_info[1] != 0;
+                if (!sink->exact) {
+                    sink->entries = p_info[0];
+                    sink->unknown_any = sink->unknown_any || p_info[1] != 0;
+                }
                 for (uint32_t i = 0; i < m; ++i) sink->max_count = std::max(sink->max_count, std::min(p_cnt[i], k));
             }
             pos = end;
@@ -2394,6 +2403,99 @@ int isccsearch_simprint_score(isccsearch_handle* h, uint32_t table, uint32_t nq,
         memcpy(out_chunks, po + chunk_off, (size_t)info[3] * sizeof(isccsearch_simprint_chunk));
         memcpy(out_chunk_words, po + words_off, (size_t)info[3] * W * 8);
     }
+    return 0;
+}
+
+// Hard-boundary simprint search with its scoring on the device (lmdb_ops.py:169-301); see include/isccsearch.h.
+int isccsearch_simprint_exact(isccsearch_handle* h, uint32_t table, uint32_t n_distinct, const uint64_t* q_words,
+                              uint32_t n_given, const uint32_t* given, uint32_t queried, uint32_t dup_limit, double threshold, uint32_t limit,
+                              isccsearch_simprint_result* out_results, isccsearch_simprint_chunk* out_chunks, uint32_t* out_info) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (dup_limit < 1) return fail(-EINVAL, "dup_limit must be >= 1");
+    if (limit < 1) return fail(-EINVAL, "limit must be >= 1");
+    if (!out_info) return fail(-EINVAL, "NULL argument");
+    out_info[0] = out_info[1] = out_info[2] = out_info[3] = 0;
+    if (n_distinct == 0 || n_given == 0) return 0;
+    if (!q_words || !given || !out_results) return fail(-EINVAL, "NULL argument");
+    if (n_distinct > isksp::MAX_QUERY_SIMPRINTS || n_given > isksp::MAX_QUERY_SIMPRINTS)
+        return fail(-E2BIG, "%u / %u query simprints exceed the %u one scoring call takes", n_distinct, n_given, isksp::MAX_QUERY_SIMPRINTS);
+    if (queried < n_given) return fail(-EINVAL, "queried (%u) counts every query simprint as given: it cannot be below n_given (%u)", queried, n_given);
+    if (!(threshold == threshold)) return fail(-EINVAL, "threshold is not a number");
+    for (uint32_t g = 0; g < n_given; ++g)
+        if (given[g] >= n_distinct) return fail(-EINVAL, "given[%u] = %u is no index into the %u distinct simprints", g, given[g], n_distinct);
+    std::lock_guard<std::mutex> lk(h->mu);
+    Table* tp;
+    int rc = get_table(h, table, tp);
+    if (rc) return rc;
+    Table& t = *tp;
+    if (t.metric != ISCCSEARCH_METRIC_HAMMING || t.key_words != 2)
+        return fail(-EINVAL, "simprint scoring is defined for fixed-length (Hamming) tables with 128-bit chunk-pointer keys");
+    Segment& s = t.seg[t.max_bytes];
+    if (s.n == 0) return 0;
+    HIPOK(hipSetDevice(h->device));
+    h->stats.searches += 1;
+    const uint32_t k = std::min<uint32_t>(dup_limit, ISCCSEARCH_MAX_K), nd = n_distinct, ng = n_given;
+    if ((rc = h->d_sp_rec.ensure((size_t)nd * k))) return rc;
+    if ((rc = h->d_sp_cnt.ensure(nd))) return rc;
+    if ((rc = h->d_sp_freqq.ensure(nd))) return rc;
+    if ((rc = h->d_sp_dofg.ensure(ng))) return rc;
+    if ((rc = h->d_sp_nbest.ensure(ng))) return rc;
+    if ((rc = h->d_sp_unknown.ensure(ng))) return rc;
+    if ((rc = h->d_sp_offs.ensure(ng))) return rc;
+    if ((rc = h->d_sp_nassets.ensure(1))) return rc;
+    ScoreSink sink;
+    sink.exact = true;
+    auto bind = [&]() {
+        isksp::Buffers& b = sink.buf;
+        b.rec = reinterpret_cast<const isccsearch_record*>(h->d_sp_rec.p);
+        b.rows = nullptr; b.best = nullptr; b.nbest = h->d_sp_nbest.p; b.offs = h->d_sp_offs.p;
+        b.freq_q = h->d_sp_freqq.p; b.unknown = h->d_sp_unknown.p; b.n_assets = h->d_sp_nassets.p;
+        for (int i = 0; i < 2; ++i) {
+            b.c_asset[i] = h->d_sp_asset[i].p; b.c_entry[i] = h->d_sp_entry[i].p;
+            b.score[i] = h->d_sp_score[i].p; b.order[i] = h->d_sp_order[i].p;
+        }
+        b.matches = h->d_sp_matches.p; b.ws = nullptr; b.idf_q = nullptr;
+        b.temp = h->d_sp_temp.p; b.temp_bytes = h->d_sp_temp.n;
+    };
+    bind();
+    // every row equal to a query simprint, ascending key, at most dup_limit per simprint (lmdb_ops.py:197-210): the lists stay on the device
+    if ((rc = search_locked(h, table, nd, q_words, nullptr, k, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &sink))) return rc;
+    out_info[2] = sink.max_count;
+    // hits per given simprint and their offsets; the number of entries comes back with one small copy
+    HIPOK(hipMemcpyAsync(h->d_sp_dofg.p, given, (size_t)ng * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    if ((rc = h->d_block.ensure(isksp::INFO_WORDS * sizeof(uint32_t)))) return rc;
+    if ((rc = h->p_block.ensure(isksp::INFO_WORDS * sizeof(uint32_t)))) return rc;
+    uint32_t* const d_info = reinterpret_cast<uint32_t*>(h->d_block.p);
+    HIPOK(isksp::exact_prepare(sink.buf, h->d_sp_cnt.p, h->d_sp_dofg.p, nd, ng, k, d_info, h->stream));
+    HIPOK(hipMemcpyAsync(h->p_block.p, d_info, isksp::INFO_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    const uint32_t entries = reinterpret_cast<const uint32_t*>(h->p_block.p)[0];
+    if (entries == 0) return 0;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = h->d_sp_asset[i].ensure(entries))) return rc;
+        if ((rc = h->d_sp_entry[i].ensure(entries))) return rc;
+        if ((rc = h->d_sp_score[i].ensure(entries))) return rc;
+        if ((rc = h->d_sp_order[i].ensure(entries))) return rc;
+    }
+    if ((rc = h->d_sp_matches.ensure(entries))) return rc;
+    if ((rc = h->d_sp_temp.ensure(isksp::sort_temp_bytes(entries)))) return rc;
+    bind();
+    const size_t res_off = 16, chunk_off = res_off + (size_t)limit * sizeof(isccsearch_simprint_result);
+    const size_t chunk_cap = out_chunks ? entries : 0;
+    if ((rc = h->p_sp_out.ensure(chunk_off + chunk_cap * sizeof(isccsearch_simprint_chunk)))) return rc;
+    unsigned char* const po = h->p_sp_out.p;
+    isksp::ExactArgs ea{};
+    ea.nd = nd; ea.ng = ng; ea.k = k; ea.entries = entries; ea.limit = limit; ea.queried = queried;
+    ea.d_of_g = h->d_sp_dofg.p; ea.threshold = threshold;
+    ea.out_info = reinterpret_cast<uint32_t*>(po);
+    ea.out_results = reinterpret_cast<isccsearch_simprint_result*>(po + res_off);
+    ea.out_chunks = out_chunks ? reinterpret_cast<isccsearch_simprint_chunk*>(po + chunk_off) : nullptr;
+    HIPOK(isksp::queue_exact(sink.buf, ea, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    const uint32_t* info = reinterpret_cast<const uint32_t*>(po);
+    out_info[0] = info[0]; out_info[1] = info[1]; out_info[3] = info[3];
+    memcpy(out_results, po + res_off, (size_t)info[0] * sizeof(isccsearch_simprint_result));
+    if (out_chunks) memcpy(out_chunks, po + chunk_off, (size_t)info[3] * sizeof(isccsearch_simprint_chunk));
     return 0;
 }
 

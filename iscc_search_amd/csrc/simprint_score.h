@@ -84,4 +84,17 @@ struct ScoreArgs {
 // sort by asset -> score -> sort by score -> emit
 hipError_t queue_score(Buffers& b, const ScoreArgs& a, hipStream_t stream);
 
+// Hard-boundary requests (search_simprints_exact, lmdb_ops.py:169-301).  Buffers: rec = the collision lists [nd][k] of the DISTINCT
+// query simprints, freq_q [nd] their document frequencies, nbest / unknown / offs sized for the GIVEN simprints [ng].
+hipError_t exact_prepare(const Buffers& b, const uint32_t* cnt, const uint32_t* d_of_g, uint32_t nd, uint32_t ng, uint32_t k, uint32_t* info, hipStream_t stream);
+struct ExactArgs {
+    uint32_t nd, ng, k, entries, limit, queried;
+    const uint32_t* d_of_g;         // [ng] device: distinct lookup of every given simprint
+    double threshold;
+    isccsearch_simprint_result* out_results;   // pinned [limit]
+    isccsearch_simprint_chunk* out_chunks;     // pinned, nullable [entries]
+    uint32_t* out_info;                        // pinned [4]
+};
+hipError_t queue_exact(Buffers& b, const ExactArgs& a, hipStream_t stream);
+
 }  // namespace isksp

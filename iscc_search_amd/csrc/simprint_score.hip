@@ -306,6 +306,9 @@ struct EmitParams {
     uint64_t* out_chunk_words;
     uint32_t* out_info;
     uint32_t limit, k, W, dup_limit;
+    // hard-boundary requests (queue_exact): an entry is (given simprint g) * k + rank; its record belongs to distinct lookup d_of_g[g]
+    const uint32_t* d_of_g;         // nullptr: the approximate path
+    const uint32_t* freq_d;         // document frequency per distinct lookup
 };
 __global__ __launch_bounds__(BLOCK) void emit_kernel(const EmitParams p) {
     __shared__ uint32_t s_first;
@@ -335,18 +338,164 @@ __global__ __launch_bounds__(BLOCK) void emit_kernel(const EmitParams p) {
     if (!p.out_chunks) return;
     for (uint32_t j = tid; j < m; j += BLOCK) {
         const uint32_t ent = p.entry[e + j];
+        isccsearch_simprint_chunk c;
+        c.query = ent / p.k;
+        c.reserved = 0;
+        if (p.d_of_g) {                       // a collision: stored simprint == query simprint, score 1.0 (lmdb_ops.py:228-235)
+            const uint32_t d = p.d_of_g[c.query];
+            c.key_lo = p.rec[(uint64_t)d * p.k + ent % p.k].key_lo;
+            c.hamming = 0;
+            c.freq = p.freq_d[d];
+            p.out_chunks[at + j] = c;
+            continue;
+        }
         const isccsearch_record& rec = p.rec[ent];
         const uint32_t row = p.rows[ent];
-        isccsearch_simprint_chunk c;
         c.key_lo = rec.key_lo;
-        c.query = ent / p.k;
         c.hamming = rec.hamming;
         c.freq = p.dup_limit ? p.freq_col[row] : 1u;
-        c.reserved = 0;
         p.out_chunks[at + j] = c;
         for (uint32_t w = 0; w < p.W; ++w) p.out_chunk_words[(uint64_t)(at + j) * p.W + w] = p.col[w][row];
     }
 }
+
+// =====================================================================================================================
+// Hard-boundary requests: search_simprints_exact (iscc_search/indexes/simprint/lmdb_ops.py:169-301) on the device.
+// Input: the collision lists of the DISTINCT query simprints (records [nd][k] of a range-limited search at distance 0: every row
+// equal to the query, ascending key = the order LMDB iterates the duplicates of a simprint key, k = dup_limit) and, for every query
+// simprint AS GIVEN (repeats included, :197), the distinct lookup it maps to.
+//   exact_freq_kernel     document frequency of every looked-up simprint: distinct assets in its list (:213-215)
+//   exact_count_kernel    hits of every given simprint = length of its lookup's list -> offsets (offsets_kernel)
+//   exact_compact_kernel  entries (asset, g * k + rank) in visiting order (given simprint, then key)
+//   [stable sort by asset]
+//   exact_weights_kernel  per sorted entry: its lookup d and that lookup's frequency, contiguous
+//   exact_score_kernel    per asset (thread at the head of its run): coverage x quality (:252-301) -- distinct matched query
+//                         simprints in first-seen order (a bit per lookup in the thread's LDS row), min / max frequency, then the
+//                         min-max normalised inverse frequencies summed in that order; score < threshold: dropped (:222-223)
+// =====================================================================================================================
+__global__ __launch_bounds__(BLOCK) void exact_freq_kernel(const isccsearch_record* rec, const uint32_t* cnt, uint32_t* freq_d, uint32_t k) {
+    __shared__ uint32_t total;
+    const uint32_t d = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    const uint32_t n = cnt[d] < k ? cnt[d] : k;
+    const isccsearch_record* r = rec + (uint64_t)d * k;
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < n; i += BLOCK) mine += (i == 0 || r[i].key_hi != r[i - 1].key_hi) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((tid & 63) == 0 && mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (tid == 0) freq_d[d] = total;
+}
+
+__global__ __launch_bounds__(BLOCK) void exact_count_kernel(const uint32_t* cnt, const uint32_t* d_of_g, uint32_t* hits, uint32_t* zero, uint32_t ng, uint32_t k) {
+    const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+    if (g < ng) {
+        const uint32_t c = cnt[d_of_g[g]];
+        hits[g] = c < k ? c : k;
+        zero[g] = 0;                      // (offsets_kernel's "unknown" input: nothing is unknown here)
+    }
+}
+
+struct ExactCompactParams {
+    const isccsearch_record* rec;
+    const uint32_t* d_of_g;
+    const uint32_t* hits;
+    const uint32_t* offs;
+    uint64_t* c_asset;
+    uint32_t* c_entry;
+    uint32_t k;
+};
+__global__ __launch_bounds__(BLOCK) void exact_compact_kernel(const ExactCompactParams p) {
+    const uint32_t g = blockIdx.x, n = p.hits[g], at = p.offs[g];
+    const isccsearch_record* r = p.rec + (uint64_t)p.d_of_g[g] * p.k;
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) { p.c_asset[at + i] = r[i].key_hi; p.c_entry[at + i] = g * p.k + i; }
+}
+
+__global__ __launch_bounds__(BLOCK) void exact_weights_kernel(const uint32_t* entry, const uint32_t* d_of_g, const uint32_t* freq_d, uint32_t* e_d, uint32_t* e_f,
+                                                              uint32_t* n_assets, uint32_t entries, uint32_t k) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t == 0) *n_assets = 0;
+    if (t < entries) {
+        const uint32_t d = d_of_g[entry[t] / k];
+        e_d[t] = d;
+        e_f[t] = freq_d[d];
+    }
+}
+
+struct ExactScoreParams {
+    const uint64_t* asset;          // sorted
+    const uint32_t* e_d;
+    const uint32_t* e_f;
+    double* score;
+    uint32_t* order;
+    uint32_t* matches;
+    uint32_t* n_assets;
+    uint32_t entries, words, queried;
+    double threshold;
+};
+__global__ void exact_score_kernel(const ExactScoreParams p) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(smem);
+    const uint32_t T = blockDim.x, tid = threadIdx.x;
+    const uint32_t e = blockIdx.x * T + tid;
+    bool counted = false;
+    if (e < p.entries) {
+        const uint64_t a = p.asset[e];
+        const bool head = e == 0 || p.asset[e - 1] != a;
+        p.order[e] = e;
+        double score = -1.0;
+        uint32_t len = 0;
+        if (head) {
+            // query_to_best_freq (:277-283): one entry per distinct matched query simprint, in first-seen order; the frequency of a
+            // collision's stored simprint is that of the query simprint itself, so "best" is that one value
+            for (uint32_t w = 0; w < p.words; ++w) mask[w * T + tid] = 0;
+            uint32_t distinct = 0, fmin = 0xFFFFFFFFu, fmax = 0;
+            uint32_t j = e;
+            for (; j < p.entries && p.asset[j] == a; ++j) {
+                const uint32_t d = p.e_d[j], f = p.e_f[j];
+                const unsigned long long bit = 1ull << (d & 63);
+                unsigned long long& word = mask[(d >> 6) * T + tid];
+                if (!(word & bit)) {
+                    word |= bit;
+                    distinct += 1;
+                    fmin = f < fmin ? f : fmin;
+                    fmax = f > fmax ? f : fmax;
+                }
+            }
+            len = j - e;
+            double quality = 1.0;
+            if (distinct > 1 && fmin != fmax) {                       // (:291-299)
+                const double min_inv = 1.0 / (double)fmax, max_inv = 1.0 / (double)fmin;
+                const double span = max_inv - min_inv;
+                for (uint32_t w = 0; w < p.words; ++w) mask[w * T + tid] = 0;
+                double sum = 0.0;
+                for (uint32_t i = e; i < j; ++i) {
+                    const uint32_t d = p.e_d[i];
+                    const unsigned long long bit = 1ull << (d & 63);
+                    unsigned long long& word = mask[(d >> 6) * T + tid];
+                    if (!(word & bit)) {
+                        word |= bit;
+                        const double inv = 1.0 / (double)p.e_f[i];
+                        const double term = (inv - min_inv) / span;
+                        sum = sum + term;
+                    }
+                }
+                quality = sum / (double)distinct;
+            }
+            const double coverage = (double)distinct / (double)p.queried;
+            score = coverage * quality;
+            if (score < p.threshold) score = -1.0;                    // (:222-223) dropped: sorts behind every kept asset
+            else counted = true;
+        }
+        p.score[e] = score;
+        p.matches[e] = len;
+    }
+    const unsigned long long kept = __ballot(counted);
+    if ((tid & 63) == 0 && kept) atomicAdd(p.n_assets, (uint32_t)__popcll(kept));
+}
+
 
 uint32_t log2_slots(uint32_t k) {   // hash slots of mark_kernel: the power of two >= 2 k (>= 64)
     uint32_t l = 6;
@@ -381,6 +530,44 @@ hipError_t queue_batch(const Buffers& b, const BatchArgs& a, hipStream_t stream)
     hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(BLOCK), 0, stream, b.nbest + a.pos, b.unknown + a.pos, b.offs + a.pos, a.m, a.base, a.info);
     CompactParams cp{b.rec + off, b.best + off, b.offs + a.pos, b.c_asset[0], b.c_entry[0], a.k, a.pos};
     hipLaunchKernelGGL(compact_kernel, dim3(a.m), dim3(BLOCK), 0, stream, cp);
+    return hipGetLastError();
+}
+
+hipError_t queue_exact(Buffers& b, const ExactArgs& a, hipStream_t stream) {
+    hipError_t e;
+    // (the caller has run exact_prepare: hits / offsets / entries are in place and `entries` is known)
+    ExactCompactParams cp{b.rec, a.d_of_g, b.nbest, b.offs, b.c_asset[0], b.c_entry[0], a.k};
+    hipLaunchKernelGGL(exact_compact_kernel, dim3(a.ng), dim3(BLOCK), 0, stream, cp);
+    size_t bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.c_asset[0], b.c_asset[1], b.c_entry[0], b.c_entry[1], a.entries, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    // (the outputs of the second sort are free until it runs: the per-entry lookup index and frequency live there meanwhile)
+    uint32_t* const e_d = b.order[1];
+    uint32_t* const e_f = reinterpret_cast<uint32_t*>(b.score[1]);
+    hipLaunchKernelGGL(exact_weights_kernel, dim3((a.entries + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, b.c_entry[1], a.d_of_g, b.freq_q, e_d, e_f, b.n_assets, a.entries, a.k);
+    const uint32_t words = (a.nd + 63) / 64;
+    const uint32_t T = words <= 32 ? 256 : (words <= 64 ? 128 : 64);
+    if (words > MAX_QUERY_SIMPRINTS / 64) return hipErrorInvalidValue;
+    ExactScoreParams sp{b.c_asset[1], e_d, e_f, b.score[0], b.order[0], b.matches, b.n_assets, a.entries, words, a.queried, a.threshold};
+    hipLaunchKernelGGL(exact_score_kernel, dim3((a.entries + T - 1) / T), dim3(T), (size_t)words * T * 8, stream, sp);
+    bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs_desc(b.temp, bytes, b.score[0], b.score[1], b.order[0], b.order[1], a.entries, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    EmitParams ep{};
+    ep.score = b.score[1]; ep.order = b.order[1]; ep.asset = b.c_asset[1]; ep.entry = b.c_entry[1]; ep.matches = b.matches;
+    ep.n_assets = b.n_assets; ep.rec = b.rec; ep.rows = nullptr; ep.freq_col = nullptr;
+    ep.out_results = a.out_results; ep.out_chunks = a.out_chunks; ep.out_chunk_words = nullptr; ep.out_info = a.out_info;
+    ep.limit = a.limit; ep.k = a.k; ep.W = 0; ep.dup_limit = 0;
+    ep.d_of_g = a.d_of_g; ep.freq_d = b.freq_q;
+    hipLaunchKernelGGL(emit_kernel, dim3(a.limit < a.entries ? a.limit : a.entries), dim3(BLOCK), 0, stream, ep);
+    return hipGetLastError();
+}
+
+// document frequencies of the lookups, hits per given simprint and their offsets; info[0] = entries (travels to the host)
+hipError_t exact_prepare(const Buffers& b, const uint32_t* cnt, const uint32_t* d_of_g, uint32_t nd, uint32_t ng, uint32_t k, uint32_t* info, hipStream_t stream) {
+    hipLaunchKernelGGL(exact_freq_kernel, dim3(nd), dim3(BLOCK), 0, stream, b.rec, cnt, b.freq_q, k);
+    hipLaunchKernelGGL(exact_count_kernel, dim3((ng + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, cnt, d_of_g, b.nbest, b.unknown, ng, k);
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(BLOCK), 0, stream, b.nbest, b.unknown, b.offs, ng, 0u, info);
     return hipGetLastError();
 }
 

@@ -394,6 +394,27 @@ class HipTable:
         n, c = int(info[0]), int(info[3])
         return results[:n], (chunks[:c] if detailed else None), (words[:c] if detailed else None), tuple(int(x) for x in info)
 
+    def simprint_exact(self, q_words, given, queried, dup_limit, threshold, limit, detailed):
+        # type: (np.ndarray, np.ndarray, int, int, float, int, bool) -> tuple
+        """
+        Hard-boundary search + coverage x quality scoring in one call (``isccsearch_simprint_exact``: ``lmdb_ops.py:169-301``).
+        ``q_words`` = the distinct query simprints, ``given`` = for every query simprint as given its index among them.
+        Returns (results, chunks or None, info).
+        """
+        q_words = self._words(q_words)
+        given = np.ascontiguousarray(given, dtype=np.uint32)
+        limit = int(limit)
+        results = np.empty(limit, dtype=_lib.SIMPRINT_RESULT_DTYPE)
+        info = np.zeros(4, dtype=np.uint32)
+        cap = int(min(dup_limit, _lib.MAX_K)) * given.shape[0]
+        chunks = np.empty(cap, dtype=_lib.SIMPRINT_CHUNK_DTYPE) if detailed else None
+        if q_words.shape[0] and given.shape[0]:
+            _lib.check(self.engine._lib.isccsearch_simprint_exact(
+                self.engine.handle, self.id, q_words.shape[0], _lib.ptr(q_words), given.shape[0], _lib.ptr(given), int(queried), int(dup_limit),
+                float(threshold), limit, _lib.ptr(results), _lib.ptr(chunks), _lib.ptr(info)))
+        n, c = int(info[0]), int(info[3])
+        return results[:n], (chunks[:c] if detailed else None), tuple(int(x) for x in info)
+
     def search_device(self, q_words, q_nbytes, k, d_records_ptr, d_counts_ptr, max_hamming=None, consumer_stream=None, hint=None):
         # type: (np.ndarray, np.ndarray | None, int, int, int, int | None, int | None, int | None) -> None
         """

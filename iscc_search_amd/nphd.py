@@ -409,11 +409,23 @@ class HipIndex128:
         """Whether the table behind this index scores simprint matches itself (``isccsearch_simprint_score``; a sharded table does not)."""
         return hasattr(self._table, "simprint_score")
 
+    @property
+    def scores_exact_on_device(self):
+        # type: () -> bool
+        """Whether the table scores hard-boundary (collision) searches itself (``isccsearch_simprint_exact``)."""
+        return hasattr(self._table, "simprint_exact")
+
     def score_assets(self, vectors, count, max_hamming, threshold, limit, total_assets, dup_limit, detailed):
         # type: (np.ndarray, int, int | None, float, int, int, int, bool) -> tuple
         """``HipTable.simprint_score`` for byte vectors: search + scoring of ``usearch_core.py:137-269`` in one device round trip."""
         q_words, _ = pack_bytes(self._vectors(vectors), self._table.max_words)
         return self._table.simprint_score(q_words, count, max_hamming, threshold, limit, total_assets, dup_limit, detailed)
+
+    def exact_assets(self, vectors, given, queried, dup_limit, threshold, limit, detailed):
+        # type: (np.ndarray, np.ndarray, int, int, float, int, bool) -> tuple
+        """``HipTable.simprint_exact`` for byte vectors: collision search + coverage x quality scoring of ``lmdb_ops.py:169-301`` on the device."""
+        q_words, _ = pack_bytes(self._vectors(vectors), self._table.max_words)
+        return self._table.simprint_exact(q_words, given, queried, dup_limit, threshold, limit, detailed)
 
     def get_freq(self, keys, dup_limit=1000):
         # type: (list[bytes], int) -> np.ndarray

@@ -345,8 +345,35 @@ class HipSimprintIndex:
         if not simprints or len(self._index) == 0:
             return []
         nbytes = self.ndim // 8
-        distinct = [sp for sp in dict.fromkeys(bytes(s) for s in simprints) if len(sp) == nbytes]
-        hits = {}
+        given = [bytes(s) for s in simprints]
+        distinct = [sp for sp in dict.fromkeys(given) if len(sp) == nbytes]
+        if distinct and self._index.scores_exact_on_device and len(given) <= MAX_SCORED_SIMPRINTS:
+            return self._search_exact_device(given, distinct, limit, threshold, detailed, dup_limit)
+        return self._search_exact_host(given, distinct, limit, threshold, detailed, dup_limit)
+
+    def _search_exact_device(self, given, distinct, limit, threshold, detailed, dup_limit):
+        # type: (list[bytes], list[bytes], int, float, bool, int) -> list[SimprintMatchRaw]
+        """
+        ``lmdb_ops.search_simprints_exact`` in ONE library call (``isccsearch_simprint_exact``): the collision lists stay in device
+        memory; document frequencies, the matches of every asset in visiting order, coverage x quality in the reference's float64
+        operations, threshold, order and cut are kernels of ``csrc/simprint_score.hip``.
+        """
+        index_of = {sp: i for i, sp in enumerate(distinct)}
+        valid = [sp for sp in given if sp in index_of]              # (a simprint of another length matches nothing)
+        lookups = np.fromiter((index_of[sp] for sp in valid), dtype=np.uint32, count=len(valid))
+        results, chunks, _ = self._index.exact_assets(_pack_simprints(distinct), lookups, len(given), max(1, dup_limit), threshold, limit, detailed)
+        body = [a.to_bytes(8, "big") for a in results["asset"].tolist()]
+        scores, matches = results["score"].tolist(), results["matches"].tolist()
+        if not detailed:
+            return [SimprintMatchRaw(b, s, len(given), m, None) for b, s, m in zip(body, scores, matches)]
+        key_lo = chunks["key_lo"]
+        cols = zip(chunks["query"].tolist(), (key_lo >> np.uint64(32)).tolist(), (key_lo & np.uint64(0xFFFFFFFF)).tolist(), chunks["freq"].tolist())
+        detail = [MatchedChunkRaw(valid[g], valid[g], 1.0, o, z, f) for g, o, z, f in cols]
+        return [SimprintMatchRaw(b, s, len(given), m, detail[f : f + m]) for b, s, m, f in zip(body, scores, matches, results["first_chunk"].tolist())]
+
+    def _search_exact_host(self, simprints, distinct, limit, threshold, detailed, dup_limit):
+        # type: (list[bytes], list[bytes], int, float, bool, int) -> list[SimprintMatchRaw]
+        """The same search scored on the host (tables sharded over several GPUs; the checker of the device path in the tests)."""
         hits = {}        # distinct query simprint -> [(asset body, offset, size)] in ascending key order
         if distinct:
             # A simprint's collisions are few: a short list first (64 records per query to select, copy and unpack instead of
@@ -378,7 +405,6 @@ class HipSimprintIndex:
         asset_matches = defaultdict(list)   # asset body -> [(query simprint, offset, size)]
         doc_freq = {}
         for sp in simprints:                # as given: a repeated query simprint is matched again (:197)
-            sp = bytes(sp)
             found = hits.get(sp)
             if not found:
                 continue

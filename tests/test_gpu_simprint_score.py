@@ -297,3 +297,64 @@ def test_concurrent_requests_and_writers(engine):
         t.join()
     assert errors == []
     index.close()
+
+
+@pytest.mark.parametrize("ndim", [64, 128, 256])
+def test_hard_boundary_search_scored_on_the_device_equals_the_host_scoring(engine, ndim):
+    """
+    ``isccsearch_simprint_exact`` against ``HipSimprintIndex._search_exact_host`` (which the CPU tier holds to the reference's
+    literals and to a model of the LMDB dupsort walk): scores ``==``, order, matches and chunks -- repeated query simprints, a
+    simprint of another length, thresholds that drop assets, limits that cut, dup_limit below / above the collision counts.
+    """
+    rng = np.random.default_rng(7000 + ndim)
+    nb = ndim // 8
+    pool = [rng.integers(0, 256, size=nb, dtype=np.uint8).tobytes() for _ in range(30)]
+    keys, vecs, seen = [], [], set()
+    ids = [0xFFFFFFFFFFFFFFFF, 0] + list(range(1, 120))
+    while len(keys) < 2500:
+        body = ids[int(rng.integers(0, len(ids)))].to_bytes(8, "big")
+        off, size = int(rng.integers(0, 60)), int(rng.integers(1, 4))
+        if (body, off, size) in seen:
+            continue
+        seen.add((body, off, size))
+        # a skewed pool: a few simprints collide hundreds of times, most a few times
+        sp = pool[min(int(rng.exponential(4.0)), len(pool) - 1)]
+        keys.append(pack_chunk_pointer(body, off, size))
+        vecs.append(np.frombuffer(sp, dtype=np.uint8))
+    index = HipSimprintIndex(engine, ndim=ndim)
+    index.add_raw(keys, vecs)
+    absent = rng.integers(0, 256, size=nb, dtype=np.uint8).tobytes()
+    cases = [
+        [pool[0]],
+        [pool[0], pool[1], pool[0], pool[5], absent, pool[29], b"\x01\x02\x03"],
+        [pool[i % 30] for i in range(70)],
+        [absent],
+    ]
+    for query in cases:
+        distinct = [sp for sp in dict.fromkeys(query) if len(sp) == nb]
+        for limit, threshold, dup_limit in ((10, 0.0, 1000), (3, 0.0, 25), (50, 0.2, 70), (1000, 0.05, 1000), (5, 0.9, 1)):
+            got = index.search_exact(query, limit=limit, threshold=threshold, detailed=True, dup_limit=dup_limit)
+            want = index._search_exact_host(query, distinct, limit, threshold, True, dup_limit)
+            assert [(r.iscc_id_body, r.score, r.matches, r.queried) for r in got] == [(r.iscc_id_body, r.score, r.matches, r.queried) for r in want]
+            for g, w in zip(got, want):
+                assert [(c.query, c.match, c.score, c.offset, c.size, c.freq) for c in g.chunks] == [(c.query, c.match, c.score, c.offset, c.size, c.freq) for c in w.chunks]
+            plain = index.search_exact(query, limit=limit, threshold=threshold, detailed=False, dup_limit=dup_limit)
+            assert [(r.iscc_id_body, r.score, r.matches) for r in plain] == [(r.iscc_id_body, r.score, r.matches) for r in want] and all(r.chunks is None for r in plain)
+    assert index.search_exact([pool[0]] * 3 + [pool[2]], limit=5, detailed=True)[0].queried == 4
+    index.close()
+
+
+def test_hard_boundary_search_with_more_lookups_than_one_batch(engine):
+    rng = np.random.default_rng(31)
+    pool = [rng.integers(0, 256, size=16, dtype=np.uint8).tobytes() for _ in range(1300)]
+    keys = [pack_chunk_pointer((1 + i % 211).to_bytes(8, "big"), i, 1) for i in range(4000)]
+    vecs = [np.frombuffer(pool[i % len(pool)], dtype=np.uint8) for i in range(4000)]
+    index = HipSimprintIndex(engine, ndim=128)
+    index.add_raw(keys, vecs)
+    query = pool[:1200] + pool[:100]
+    got = index.search_exact(query, limit=30, threshold=0.0, detailed=True)
+    want = index._search_exact_host(query, list(dict.fromkeys(query)), 30, 0.0, True, 1000)
+    assert [(r.iscc_id_body, r.score, r.matches) for r in got] == [(r.iscc_id_body, r.score, r.matches) for r in want] and len(got) == 30
+    for g, w in zip(got, want):
+        assert [(c.query, c.offset, c.size, c.freq) for c in g.chunks] == [(c.query, c.offset, c.size, c.freq) for c in w.chunks]
+    index.close()
