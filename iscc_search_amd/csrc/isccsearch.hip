@@ -1685,6 +1685,11 @@ struct ScoreSink {
     uint32_t max_count = 0;     // longest neighbour list
     bool unknown_any = false;   // some query's own document frequency could not be read off its list
     bool exact = false;         // isccsearch_simprint_exact: the lists are collision lists; only their lengths are kept per batch (no marking)
+    // ... and when ONE batch holds every lookup, its hits / offsets are prepared behind its select, so that the number of entries
+    // arrives with the batch's own synchronisation
+    const uint32_t* d_of_g = nullptr;
+    uint32_t nd = 0, ng = 0;
+    bool prepared = false;
 };
 
 // The search itself; h->mu is held by the caller.
@@ -1780,6 +1785,8 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 uint32_t* const d_info = d_cnt + m + flag_slots + m;
                 if (sink->exact) {
                     HIPOK(hipMemcpyAsync(h->d_sp_cnt.p + pos, d_cnt, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+                    if (pos == 0 && m == sink->nd && sink->d_of_g)
+                        HIPOK(isksp::exact_prepare(sink->buf, d_cnt, sink->d_of_g, sink->nd, sink->ng, k, d_info, h->stream));
                 } else {
                     isksp::BatchArgs ba{pos, m, k, d_cnt, sink->h_max, sink->dup_limit, sink->entries, d_info};
                     HIPOK(isksp::queue_batch(sink->buf, ba, h->stream));
@@ -1951,6 +1958,9 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
                 if (!sink->exact) {
                     sink->entries = p_info[0];
                     sink->unknown_any = sink->unknown_any || p_info[1] != 0;
+                } else if (pos == 0 && m == sink->nd && sink->d_of_g) {
+                    sink->entries = p_info[0];
+                    sink->prepared = true;
                 }
                 for (uint32_t i = 0; i < m; ++i) sink->max_count = std::max(sink->max_count, std::min(p_cnt[i], k));
             }
@@ -2458,18 +2468,25 @@ int isccsearch_simprint_exact(isccsearch_handle* h, uint32_t table, uint32_t n_d
         b.temp = h->d_sp_temp.p; b.temp_bytes = h->d_sp_temp.n;
     };
     bind();
+    // (the lookup of every given simprint goes up first: when one batch holds all lookups, hits and offsets are prepared behind its
+    //  select and the number of entries arrives with the batch's own synchronisation)
+    HIPOK(hipMemcpyAsync(h->d_sp_dofg.p, given, (size_t)ng * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));           // (`given` is the caller's memory)
+    sink.d_of_g = h->d_sp_dofg.p; sink.nd = nd; sink.ng = ng;
     // every row equal to a query simprint, ascending key, at most dup_limit per simprint (lmdb_ops.py:197-210): the lists stay on the device
     if ((rc = search_locked(h, table, nd, q_words, nullptr, k, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &sink))) return rc;
     out_info[2] = sink.max_count;
-    // hits per given simprint and their offsets; the number of entries comes back with one small copy
-    HIPOK(hipMemcpyAsync(h->d_sp_dofg.p, given, (size_t)ng * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    if ((rc = h->d_block.ensure(isksp::INFO_WORDS * sizeof(uint32_t)))) return rc;
-    if ((rc = h->p_block.ensure(isksp::INFO_WORDS * sizeof(uint32_t)))) return rc;
-    uint32_t* const d_info = reinterpret_cast<uint32_t*>(h->d_block.p);
-    HIPOK(isksp::exact_prepare(sink.buf, h->d_sp_cnt.p, h->d_sp_dofg.p, nd, ng, k, d_info, h->stream));
-    HIPOK(hipMemcpyAsync(h->p_block.p, d_info, isksp::INFO_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPOK(hipStreamSynchronize(h->stream));
-    const uint32_t entries = reinterpret_cast<const uint32_t*>(h->p_block.p)[0];
+    uint32_t entries = sink.entries;
+    if (!sink.prepared) {
+        // several batches of lookups: hits per given simprint and their offsets now; the number of entries comes back with one small copy
+        if ((rc = h->d_block.ensure(isksp::INFO_WORDS * sizeof(uint32_t)))) return rc;
+        if ((rc = h->p_block.ensure(isksp::INFO_WORDS * sizeof(uint32_t)))) return rc;
+        uint32_t* const d_info = reinterpret_cast<uint32_t*>(h->d_block.p);
+        HIPOK(isksp::exact_prepare(sink.buf, h->d_sp_cnt.p, h->d_sp_dofg.p, nd, ng, k, d_info, h->stream));
+        HIPOK(hipMemcpyAsync(h->p_block.p, d_info, isksp::INFO_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        entries = reinterpret_cast<const uint32_t*>(h->p_block.p)[0];
+    }
     if (entries == 0) return 0;
     for (int i = 0; i < 2; ++i) {
         if ((rc = h->d_sp_asset[i].ensure(entries))) return rc;

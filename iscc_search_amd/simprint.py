@@ -20,6 +20,7 @@ from iscc_search_amd._lib import MAX_K, MAX_SCORED_SIMPRINTS
 from iscc_search_amd.nphd import HipIndex128, words_to_key128
 
 CHUNK_POINTER_BYTES = 16
+EXACT_DEVICE_FROM = 128     # query simprints from which a hard-boundary search is scored on the device (isccsearch_simprint_exact)
 EXACT_FIRST_K = 64          # records per lookup a hard-boundary search asks for first (a full list is asked again up to dup_limit)
 DOC_FREQ_DUP_LIMIT = 1000   # duplicates looked at per simprint when counting its assets: the reference's safety cap
                             # (count_doc_freq(dup_limit=1000), lmdb_ops.py:139-166); HipIndex128.get_freq / doc_freq share it
@@ -347,7 +348,8 @@ class HipSimprintIndex:
         nbytes = self.ndim // 8
         given = [bytes(s) for s in simprints]
         distinct = [sp for sp in dict.fromkeys(given) if len(sp) == nbytes]
-        if distinct and self._index.scores_exact_on_device and len(given) <= MAX_SCORED_SIMPRINTS:
+        # (a handful of lookups: their lists are tiny and the host scores them in less time than the device path's extra launches take)
+        if distinct and self._index.scores_exact_on_device and EXACT_DEVICE_FROM <= len(given) <= MAX_SCORED_SIMPRINTS:
             return self._search_exact_device(given, distinct, limit, threshold, detailed, dup_limit)
         return self._search_exact_host(given, distinct, limit, threshold, detailed, dup_limit)
 

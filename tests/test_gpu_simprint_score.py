@@ -333,14 +333,21 @@ def test_hard_boundary_search_scored_on_the_device_equals_the_host_scoring(engin
     for query in cases:
         distinct = [sp for sp in dict.fromkeys(query) if len(sp) == nb]
         for limit, threshold, dup_limit in ((10, 0.0, 1000), (3, 0.0, 25), (50, 0.2, 70), (1000, 0.05, 1000), (5, 0.9, 1)):
-            got = index.search_exact(query, limit=limit, threshold=threshold, detailed=True, dup_limit=dup_limit)
+            if not distinct:
+                assert index.search_exact(query, limit=limit, threshold=threshold, detailed=True, dup_limit=dup_limit) == []
+                continue
+            # (search_exact itself sends requests of fewer than EXACT_DEVICE_FROM simprints to the host scoring: the device path is called directly)
+            got = index._search_exact_device(query, distinct, limit, threshold, True, dup_limit)
             want = index._search_exact_host(query, distinct, limit, threshold, True, dup_limit)
             assert [(r.iscc_id_body, r.score, r.matches, r.queried) for r in got] == [(r.iscc_id_body, r.score, r.matches, r.queried) for r in want]
             for g, w in zip(got, want):
                 assert [(c.query, c.match, c.score, c.offset, c.size, c.freq) for c in g.chunks] == [(c.query, c.match, c.score, c.offset, c.size, c.freq) for c in w.chunks]
-            plain = index.search_exact(query, limit=limit, threshold=threshold, detailed=False, dup_limit=dup_limit)
+            plain = index._search_exact_device(query, distinct, limit, threshold, False, dup_limit)
             assert [(r.iscc_id_body, r.score, r.matches) for r in plain] == [(r.iscc_id_body, r.score, r.matches) for r in want] and all(r.chunks is None for r in plain)
     assert index.search_exact([pool[0]] * 3 + [pool[2]], limit=5, detailed=True)[0].queried == 4
+    many = [pool[i % 30] for i in range(200)]                    # past EXACT_DEVICE_FROM: the public entry takes the device path itself
+    assert [(r.iscc_id_body, r.score, r.matches) for r in index.search_exact(many, limit=20, detailed=True)] == \
+           [(r.iscc_id_body, r.score, r.matches) for r in index._search_exact_host(many, list(dict.fromkeys(many)), 20, 0.0, True, 1000)]
     index.close()
 
 

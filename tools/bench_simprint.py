@@ -34,7 +34,7 @@ CHUNKS_PER_ASSET = 40
 class DeviceClock:
     """Wall time spent inside the index's device entry points (each ends with the results on the host)."""
 
-    NAMES = ("search_arrays", "search_within", "get_many", "get_freq", "doc_freq", "score_assets")
+    NAMES = ("search_arrays", "search_within", "get_many", "get_freq", "doc_freq", "score_assets", "exact_assets")
 
     def __init__(self, index):
         self.seconds = 0.0
