@@ -398,7 +398,7 @@ def main():
         # (sharded steps: every shard starts under the GLOBAL k-th distance of the previous step + 2; the merged lists are checked)
         extra["threshold_hint"] = {"steps_started_under_a_hint": sharded.hint_hits, "hints_that_did_not_hold": sharded.hint_misses,
                                    "what": "all steps of this process (gate, settle, warm-up, timed): shards started under the previous step's global k-th "
-                                           "distance + 2; a step stands only if every merged list holds k rows (sharded.py)"}
+                                           "distance + 2 (+ 1 from k = 64); a step stands only if every merged list holds k rows (sharded.py)"}
     total_queries = args.queries * args.steps
     qps = total_queries / elapsed
     out = {
