@@ -2659,7 +2659,13 @@ int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_
             batch.mark_overflow = true;
             // (sharded callers: the GLOBAL k-th distance of the previous step + margin -- every shard then lists its rows under it,
             //  tightening as it finds k of its own, and the caller accepts the merged lists only if they hold k rows per query)
-            if (radius < 0 && hint >= 0) batch.self_hint = hint;
+            // ... a SMALL batch (the protocol's per-unit searches on a sharded index) takes the hint as the radius of one range-limited
+            // pass -- radius_init + collect + select instead of bootstrap + levels + picks + collect -- as search_locked's speculative
+            // pass does on one GPU; same contract: the table's nearest rows within the hint, fewer than k if it was too tight
+            if (radius < 0 && hint >= 0) {
+                if (h->speculate && nq <= h->spec_max_queries) batch.radius = hint;
+                else batch.self_hint = hint;
+            }
             if ((rc = batch.begin(q_words))) return rc;
             HIPOK(hipEventRecord(h->ev_done, h->stream));
             HIPOK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->ev_done, 0));

@@ -245,7 +245,7 @@ class ShardedTable:
         table -- with ONE exchange: every shard runs its local searches back to back, their blocks travel in one all-gather, each
         part is merged on its own.  ``items`` = [(ShardedTable, q_words, q_nbytes, k, max_hamming | None)], queries of one length
         per item; returns the results in order, or None when the items cannot share an exchange (the caller then runs them one
-        by one).  No threshold hints here: these are single queries, whose local searches speculate on their own.
+        by one).
         """
         import torch
 
@@ -254,9 +254,20 @@ class ShardedTable:
             return None            # (two items on one table with one block size would share that table's block buffer)
         if any(t.world_size != first.world_size or t.group is not first.group for t, *_ in items):
             return None
-        blocks = []
+        # every item's shards start under the GLOBAL k-th distance its table's previous search of this shape ended at (as `_search`):
+        # the per-unit searches of a request then cost each shard one range-limited pass instead of bootstrap + levels
+        blocks, states = [], []
         for t, q_words, q_nbytes, k, max_hamming in items:
-            blocks.append(t.ops.local_search(q_words, q_nbytes, k) if max_hamming is None else t.ops.local_search(q_words, q_nbytes, k, max_hamming))
+            state, how = None, {}
+            if t.use_hints and max_hamming is None:
+                qlen = None if q_nbytes is None else tuple(sorted(set(int(b) for b in np.asarray(q_nbytes))))
+                state = t._hints.setdefault((int(q_words.shape[0]).bit_length(), int(k), qlen), [None, 0, 0])
+                if state[0] is not None and state[1] == 0:
+                    how = {"hint": state[0]}
+                elif state[1]:
+                    state[1] -= 1
+            states.append((state, bool(how)))
+            blocks.append(t.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else t.ops.local_search(q_words, q_nbytes, k, max_hamming))
         share = torch.cat(blocks)
         total = share.numel()
         if share.is_cuda and first.dist.get_backend(first.group) == "gloo":
@@ -276,10 +287,29 @@ class ShardedTable:
             else:
                 part = gathered.view(t.world_size, total)[:, offset : offset + block.numel()].contiguous().view(-1)
                 res = t.ops.merge(part, t.world_size, nq, k)
-            if np.any(res[3] == COUNT_OVERFLOW):
-                # a shard could only mark an overflowed candidate list: the merged counts are the same on every rank, so every rank
-                # repeats THIS item through the synchronous path together
+            state, hinted = states[len(out)]
+            cnt = res[3]
+            full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
+            if hinted and not full:
+                # the hint was too tight for some query (or a list overflowed under it): the merged lists are the same on every rank, so
+                # every rank repeats THIS item without it together
+                t.hint_misses += 1
+                state[2] = min(2 * state[2] + 1, 15)
+                state[1] = state[2] - 1
+                res = t._exchange(q_words, q_nbytes, k, max_hamming, {})
+                cnt = res[3]
+                hinted = False
+            if np.any(cnt == COUNT_OVERFLOW):
+                # a shard could only mark an overflowed candidate list: every rank repeats THIS item through the synchronous path together
                 res = t._exchange(q_words, q_nbytes, k, max_hamming, {"synchronous": True})
+                cnt = res[3]
+            if state is not None:
+                full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
+                if hinted:
+                    t.hint_hits += 1
+                    state[0], state[2] = max(int(res[1][:, k - 1].max()) + hint_margin(k), state[0] - 1), 0
+                else:
+                    state[0] = int(res[1][:, k - 1].max()) + hint_margin(k) if full else None
             out.append(res)
             offset += block.numel()
         return out

@@ -21,6 +21,13 @@ def _queries():
     return rng.integers(0, 2**64, size=(NQ, 1), dtype=np.uint64)
 
 
+def _stored_codes(n):
+    """The codes of rows 0 .. n-1 of the synthetic table (SURVEY 8d generator), as queries: nearest neighbour at distance 0."""
+    from oracle import oracle_splitmix64_fill
+
+    return oracle_splitmix64_fill(n, SEED, stride=4).reshape(n, 1)
+
+
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -42,6 +49,31 @@ def _worker(rank, world, port, out_dir):
             out[f"s{i}"] = a
         for i, a in enumerate(sharded.search_within(q, None, 50, 14)):
             out[f"w{i}"] = a
+        # SMALL batches (the protocol's per-unit searches): from the second search of a shape on, every shard takes ONE range-limited
+        # pass under the global k-th distance of the search before (isccsearch_search_device_async with a hint); a batch of stored
+        # codes leaves a hint no random batch can hold: noticed on the merged lists, repeated without it
+        near = _stored_codes(3)
+        small = [q[:1], q[1:2], q[2:3], q[:5], q[5:10], near, q[10:13], q[13:16], q[16:17]]
+        for j, qq in enumerate(small):
+            for i, a in enumerate(sharded.search(qq, None, K)):
+                out[f"m{j}_{i}"] = a
+        # k = 1: three stored codes end at distance 0 and leave a hint of 2 bits, which three random queries cannot hold
+        for j, qq in enumerate([near, q[10:13], q[13:16]]):
+            for i, a in enumerate(sharded.search(qq, None, 1)):
+                out[f"n{j}_{i}"] = a
+        out["hints"] = np.array([sharded.hint_hits, sharded.hint_misses])
+        # the per-unit searches of one request on two tables: ONE exchange for all of them (ShardedTable.search_many), twice (the
+        # second time under the first one's hints)
+        table2 = engine.open_table(0, 1, 8)
+        table2.add_synthetic(8, hi - lo, SEED + 99, first_row=lo)
+        sharded2 = ShardedTable(HipShardOps(table2, "cuda:0"))
+        for rep in range(2):
+            fused = ShardedTable.search_many([(sharded, q[17:18], None, K, None), (sharded2, q[18:19], None, K, None), (sharded2, q[19:22], None, 3, 16)])
+            assert fused is not None
+            for j, res in enumerate(fused):
+                for i, a in enumerate(res):
+                    out[f"f{rep}_{j}_{i}"] = a
+        out["hints2"] = np.array([sharded.hint_hits + sharded2.hint_hits, sharded.hint_misses + sharded2.hint_misses])
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), **out)
     finally:
         engine.close()
@@ -72,6 +104,32 @@ def test_two_processes_two_shards_one_gpu(tmp_path):
                 np.testing.assert_array_equal(z[f"s{i}"], want_s[i], err_msg=f"rank {rank} search field {i}")
                 np.testing.assert_array_equal(z[f"w{i}"], want_w[i], err_msg=f"rank {rank} within field {i}")
     assert int(want_w[3].sum()) > 0          # the radius admits rows, so the within lists are not trivially empty
+    # the small batches, hinted from their second search on, and the fused per-unit searches
+    words2 = oracle_splitmix64_fill(ROWS, SEED + 99, stride=4).reshape(ROWS, 1)
+    small = [q[:1], q[1:2], q[2:3], q[:5], q[5:10], _stored_codes(3), q[10:13], q[13:16], q[16:17]]
+    for rank in range(2):
+        with np.load(os.path.join(tmp_path, f"r{rank}.npz")) as z:
+            for j, qq in enumerate(small):
+                want = oracle_topk(0, row_keys, words, None, qq, None, K)
+                for i in range(4):
+                    np.testing.assert_array_equal(z[f"m{j}_{i}"], want[i], err_msg=f"rank {rank} small batch {j} field {i}")
+            for j, qq in enumerate([_stored_codes(3), q[10:13], q[13:16]]):
+                want = oracle_topk(0, row_keys, words, None, qq, None, 1)
+                for i in range(4):
+                    np.testing.assert_array_equal(z[f"n{j}_{i}"], want[i], err_msg=f"rank {rank} k = 1 batch {j} field {i}")
+            assert z["hints"][0] >= 3 and z["hints"][1] >= 1, z["hints"]          # hints held, and the one left by the stored codes did not
+            fused_want = [oracle_topk(0, row_keys, words, None, q[17:18], None, K), oracle_topk(0, row_keys, words2, None, q[18:19], None, K)]
+            within = (np.zeros((3, 3), np.uint64), np.zeros((3, 3), np.uint32), np.zeros((3, 3), np.uint16), np.zeros(3, np.uint32))
+            for i in range(3):
+                kk, h, p = np_within(words2, 8, row_keys, q[19 + i], 8, 3, 16)
+                c = len(h)
+                within[0][i, :c], within[1][i, :c], within[2][i, :c], within[3][i] = kk, h, p, c
+            fused_want.append(within)
+            for rep in range(2):
+                for j, want in enumerate(fused_want):
+                    for i in range(4):
+                        np.testing.assert_array_equal(z[f"f{rep}_{j}_{i}"], want[i], err_msg=f"rank {rank} fused pass {rep} item {j} field {i}")
+            assert z["hints2"][0] > z["hints"][0]                                   # the second fused request started under the first one's hints
 
 
 def _manager_worker(rank, world, port, out_dir):
