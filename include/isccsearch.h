@@ -324,6 +324,22 @@ int isccsearch_merge_device_after(isccsearch_handle* h, uint32_t n_lists, uint32
                                   void* producer_stream,
                                   uint64_t* out_keys, uint32_t* out_hamming, uint16_t* out_prefix_bits, uint32_t* out_count);
 
+/* Several merge_device_after calls behind ONE synchronisation (the per-unit searches of one request on a sharded index share one
+ * all-gather: their merges are queued back to back and read after a single synchronisation).  Every request is shaped as the
+ * arguments of isccsearch_merge_device_after; all results together must fit the directly written result block (1 MB), else -E2BIG. */
+typedef struct isccsearch_merge_request {
+    uint32_t n_lists, nq, k;
+    int32_t key_words;
+    const void* d_records;
+    const void* d_counts;
+    uint64_t list_stride, count_stride;
+    uint64_t* out_keys;
+    uint32_t* out_hamming;
+    uint16_t* out_prefix_bits;
+    uint32_t* out_count;
+} isccsearch_merge_request;
+int isccsearch_merge_many_after(isccsearch_handle* h, uint32_t n, isccsearch_merge_request* reqs, void* producer_stream);
+
 #ifdef __cplusplus
 }
 #endif

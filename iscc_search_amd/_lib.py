@@ -31,7 +31,7 @@ EXPORTS = (
     "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_search_many", "isccsearch_doc_freq", "isccsearch_doc_freq_counted", "isccsearch_get_freq",
     "isccsearch_simprint_score", "isccsearch_simprint_exact",
     "isccsearch_search_device", "isccsearch_search_within_device", "isccsearch_merge_device",
-    "isccsearch_search_device_async", "isccsearch_merge_device_after",
+    "isccsearch_search_device_async", "isccsearch_merge_device_after", "isccsearch_merge_many_after",
 )
 
 RECORD_DTYPE = np.dtype(
@@ -94,6 +94,25 @@ class Request(ctypes.Structure):
         ("out_prefix_bits", ctypes.c_void_p),
         ("out_count", ctypes.c_void_p),
         ("status", ctypes.c_int32),
+    ]
+
+
+class MergeRequest(ctypes.Structure):
+    """``isccsearch_merge_request``: one merge of an ``isccsearch_merge_many_after`` call."""
+
+    _fields_ = [
+        ("n_lists", ctypes.c_uint32),
+        ("nq", ctypes.c_uint32),
+        ("k", ctypes.c_uint32),
+        ("key_words", ctypes.c_int32),
+        ("d_records", ctypes.c_void_p),
+        ("d_counts", ctypes.c_void_p),
+        ("list_stride", ctypes.c_uint64),
+        ("count_stride", ctypes.c_uint64),
+        ("out_keys", ctypes.c_void_p),
+        ("out_hamming", ctypes.c_void_p),
+        ("out_prefix_bits", ctypes.c_void_p),
+        ("out_count", ctypes.c_void_p),
     ]
 
 
@@ -162,6 +181,7 @@ def load_library():
         "isccsearch_merge_device": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, u64p, u32p, u16p, u32p]),
         "isccsearch_search_device_async": (i, [vp, u32, u32, u64p, u8p, u32, ctypes.c_int32, vp, vp, vp]),
         "isccsearch_merge_device_after": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, vp, u64p, u32p, u16p, u32p]),
+        "isccsearch_merge_many_after": (i, [vp, u32, ctypes.POINTER(MergeRequest), vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

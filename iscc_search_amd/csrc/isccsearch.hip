@@ -2621,6 +2621,50 @@ int isccsearch_merge_device_after(isccsearch_handle* h, uint32_t n_lists, uint32
                              out_keys, out_hamming, out_prefix_bits, out_count);
 }
 
+// Several merges behind ONE synchronisation: the per-unit searches of one request on a sharded index share one all-gather
+// (sharded.py, ShardedTable.search_many); their merges are queued back to back into distinct parts of the pinned result block
+// and read after a single hipStreamSynchronize (each merge_device_after call costs one: ~50 us per unit).
+int isccsearch_merge_many_after(isccsearch_handle* h, uint32_t n, isccsearch_merge_request* reqs, void* producer_stream) {
+    if (!h) return fail(-EINVAL, "handle is NULL");
+    if (n == 0) return 0;
+    if (!reqs) return fail(-EINVAL, "NULL argument");
+    size_t total = 0;
+    std::vector<size_t> off(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        isccsearch_merge_request& r = reqs[i];
+        if (r.nq == 0 || r.n_lists < 1 || r.k < 1 || r.k > ISCCSEARCH_MAX_K || (r.key_words != 1 && r.key_words != 2)) return fail(-EINVAL, "bad arguments (merge %u)", i);
+        if (!r.d_records || !r.d_counts || !r.out_keys || !r.out_hamming || !r.out_prefix_bits || !r.out_count) return fail(-EINVAL, "NULL argument (merge %u)", i);
+        if (r.list_stride % 8 || r.count_stride % 4 || (uintptr_t)r.d_records % 8 || (uintptr_t)r.d_counts % 4) return fail(-EINVAL, "misaligned record/count blocks (merge %u)", i);
+        off[i] = total;
+        total += ((size_t)r.nq * r.k * sizeof(isk::Record) + (size_t)r.nq * sizeof(uint32_t) + 15) & ~(size_t)15;
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPOK(hipSetDevice(h->device));
+    int rc;
+    // the kernels write their {records | counts} straight into the pinned block (mapped into the device's address space); a request
+    // whose results do not fit the direct budget goes through the ordinary call
+    if (total > DIRECT_RESULT_BYTES) return fail(-E2BIG, "merge_many: %zu bytes of results exceed the directly written block", total);
+    if ((rc = h->p_block.ensure(total))) return rc;
+    HIPOK(hipEventRecord(h->ev_producer, static_cast<hipStream_t>(producer_stream)));
+    HIPOK(hipStreamWaitEvent(h->stream, h->ev_producer, 0));
+    for (uint32_t i = 0; i < n; ++i) {
+        isccsearch_merge_request& r = reqs[i];
+        const size_t rec_bytes = (size_t)r.nq * r.k * sizeof(isk::Record);
+        isk::MergeParams mp{static_cast<const unsigned char*>(r.d_records), static_cast<const unsigned char*>(r.d_counts), r.list_stride, r.count_stride,
+                            reinterpret_cast<isk::Record*>(h->p_block.p + off[i]), reinterpret_cast<uint32_t*>(h->p_block.p + off[i] + rec_bytes), r.n_lists, r.nq, r.k};
+        hipLaunchKernelGGL(isk::merge_kernel, dim3(r.nq), dim3(isk::BLOCK), 0, h->stream, mp);
+    }
+    HIPOK(hipGetLastError());
+    HIPOK(hipStreamSynchronize(h->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        isccsearch_merge_request& r = reqs[i];
+        const size_t rec_bytes = (size_t)r.nq * r.k * sizeof(isk::Record);
+        unpack_records(reinterpret_cast<const isk::Record*>(h->p_block.p + off[i]), reinterpret_cast<const uint32_t*>(h->p_block.p + off[i] + rec_bytes), r.nq, r.k, r.key_words,
+                       nullptr, r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count);
+    }
+    return 0;
+}
+
 int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                                    const uint8_t* q_nbytes, uint32_t k, int32_t max_hamming,
                                    void* d_records, uint32_t* d_counts, void* consumer_stream) {

@@ -102,6 +102,23 @@ class HipEngine:
             _lib.check(self._lib.isccsearch_merge_device_after(*args, ctypes.c_void_p(after_stream), *outs))
         return out
 
+    def merge_many(self, merges, after_stream):
+        # type: (list[tuple], int) -> list[tuple]
+        """
+        Several ``merge_device`` calls behind ONE synchronisation (``isccsearch_merge_many_after``).
+        ``merges`` = [(n_lists, nq, k, key_words, d_records_ptr, d_counts_ptr, list_stride, count_stride)].
+        """
+        arr = (_lib.MergeRequest * len(merges))()
+        outs = []
+        for r, (n_lists, nq, k, key_words, rec, cnt, ls, cs) in zip(arr, merges):
+            out, addr = _alloc_out(nq, k, key_words)
+            outs.append(out)
+            r.n_lists, r.nq, r.k, r.key_words = n_lists, nq, k, key_words
+            r.d_records, r.d_counts, r.list_stride, r.count_stride = rec, cnt, ls, cs
+            r.out_keys, r.out_hamming, r.out_prefix_bits, r.out_count = addr
+        _lib.check(self._lib.isccsearch_merge_many_after(self.handle, len(merges), arr, ctypes.c_void_p(after_stream)))
+        return outs
+
     def search_many(self, requests):
         # type: (list[tuple]) -> list[tuple]
         """

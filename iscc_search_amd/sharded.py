@@ -112,6 +112,19 @@ class HipShardOps:
         base = gathered.data_ptr()
         return self.engine.merge_device(n_lists, nq, k, self.key_words, base, base + rec_bytes, blk, blk, after_stream=self._stream())
 
+    def merge_many(self, gathered, stride, parts):
+        """Several parts of a fused exchange merged behind ONE synchronisation; parts = [(offset, n_lists, nq, k, key_words)]; None = too large for one call."""
+        base = gathered.data_ptr()
+        merges = []
+        total = 0
+        for offset, n_lists, nq, k, key_words in parts:
+            rec_bytes, _ = block_bytes(nq, k)
+            merges.append((n_lists, nq, k, key_words, base + offset, base + offset + rec_bytes, stride, stride))
+            total += rec_bytes + nq * 4 + 16
+        if total > (1 << 20):
+            return None
+        return self.engine.merge_many(merges, self._stream())
+
     def merge_strided(self, gathered, offset, stride, n_lists, nq, k):
         """The same for a block that is one PART of every rank's share of a fused exchange: list l sits at offset + l x stride."""
         rec_bytes, _ = block_bytes(nq, k)
@@ -278,11 +291,22 @@ class ShardedTable:
             make = getattr(first.ops, "buffer", None)
             gathered = make("gathered", first.world_size * total) if make else torch.empty(first.world_size * total, dtype=share.dtype, device=share.device)
             first.dist.all_gather_into_tensor(gathered, share, group=first.group)
+        # the merges: queued back to back behind ONE synchronisation when the ops share an engine that can (HipShardOps.merge_many)
+        merged = None
+        many = getattr(first.ops, "merge_many", None)
+        if many is not None and all(getattr(t.ops, "engine", None) is first.ops.engine for t, *_ in items):
+            parts, offset = [], 0
+            for (t, q_words, _, k, _), block in zip(items, blocks):
+                parts.append((offset, t.world_size, q_words.shape[0], k, t.ops.key_words))
+                offset += block.numel()
+            merged = many(gathered, total, parts)
         out, offset = [], 0
         for (t, q_words, q_nbytes, k, max_hamming), block in zip(items, blocks):
             nq = q_words.shape[0]
             strided = getattr(t.ops, "merge_strided", None)
-            if strided is not None:
+            if merged is not None:
+                res = merged[len(out)]
+            elif strided is not None:
                 res = strided(gathered, offset, total, t.world_size, nq, k)
             else:
                 part = gathered.view(t.world_size, total)[:, offset : offset + block.numel()].contiguous().view(-1)
