@@ -316,6 +316,10 @@ int isccsearch_merge_device(isccsearch_handle* h, uint32_t n_lists, uint32_t nq,
  *                         blocks were produced on); ONE device->host copy and ONE synchronisation.  out_count[q] ==
  *                         ISCCSEARCH_COUNT_OVERFLOW reports the marker. */
 #define ISCCSEARCH_COUNT_OVERFLOW 0xFFFFFFFFu
+/* The library's stream (a hipStream_t, owned by the handle).  A host that issues the exchange between the two calls ON this
+ * stream (torch: torch.cuda.ExternalStream) and passes it as consumer_stream / producer_stream needs no event between the
+ * streams: search, exchange and merge are one in-order queue (two cross-queue hand-overs, ~12 and ~21 us per step, dropped). */
+void* isccsearch_stream(isccsearch_handle* h);
 int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_t nq, const uint64_t* q_words,
                                    const uint8_t* q_nbytes, uint32_t k, int32_t max_hamming,
                                    void* d_records, uint32_t* d_counts, void* consumer_stream);

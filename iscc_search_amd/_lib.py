@@ -31,7 +31,7 @@ EXPORTS = (
     "isccsearch_add_synthetic", "isccsearch_search", "isccsearch_search_within", "isccsearch_search_many", "isccsearch_doc_freq", "isccsearch_doc_freq_counted", "isccsearch_get_freq",
     "isccsearch_simprint_score", "isccsearch_simprint_exact",
     "isccsearch_search_device", "isccsearch_search_within_device", "isccsearch_merge_device",
-    "isccsearch_search_device_async", "isccsearch_merge_device_after", "isccsearch_merge_many_after",
+    "isccsearch_search_device_async", "isccsearch_merge_device_after", "isccsearch_merge_many_after", "isccsearch_stream",
 )
 
 RECORD_DTYPE = np.dtype(
@@ -182,6 +182,7 @@ def load_library():
         "isccsearch_search_device_async": (i, [vp, u32, u32, u64p, u8p, u32, ctypes.c_int32, vp, vp, vp]),
         "isccsearch_merge_device_after": (i, [vp, u32, u32, u32, i, vp, vp, u64, u64, vp, u64p, u32p, u16p, u32p]),
         "isccsearch_merge_many_after": (i, [vp, u32, ctypes.POINTER(MergeRequest), vp]),
+        "isccsearch_stream": (vp, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -1159,6 +1159,8 @@ int isccsearch_create(int device_id, isccsearch_handle** out) {
     return 0;
 }
 
+void* isccsearch_stream(isccsearch_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
 int isccsearch_destroy(isccsearch_handle* h) {
     if (!h) return 0;
     {
@@ -2576,8 +2578,11 @@ static int merge_device_impl(isccsearch_handle* h, uint32_t n_lists, uint32_t nq
     if (list_stride % 8 || count_stride % 4 || (uintptr_t)d_records % 8 || (uintptr_t)d_counts % 4) return fail(-EINVAL, "misaligned record/count blocks");
     if (ordered) {
         // the gathered blocks are produced on the caller's stream: order the merge behind it without a host round-trip
-        HIPOK(hipEventRecord(h->ev_producer, static_cast<hipStream_t>(producer_stream)));
-        HIPOK(hipStreamWaitEvent(h->stream, h->ev_producer, 0));
+        // (a caller that issued them on the library's own stream -- isccsearch_stream -- is ordered already)
+        if (static_cast<hipStream_t>(producer_stream) != h->stream) {
+            HIPOK(hipEventRecord(h->ev_producer, static_cast<hipStream_t>(producer_stream)));
+            HIPOK(hipStreamWaitEvent(h->stream, h->ev_producer, 0));
+        }
     }
     // The merge writes its {records | counts} straight into ONE pinned host block (page-locked memory is mapped into the
     // device's address space): 240 bytes per query cross PCIe as the kernel's own stores, and the host needs a single
@@ -2645,8 +2650,10 @@ int isccsearch_merge_many_after(isccsearch_handle* h, uint32_t n, isccsearch_mer
     // whose results do not fit the direct budget goes through the ordinary call
     if (total > DIRECT_RESULT_BYTES) return fail(-E2BIG, "merge_many: %zu bytes of results exceed the directly written block", total);
     if ((rc = h->p_block.ensure(total))) return rc;
-    HIPOK(hipEventRecord(h->ev_producer, static_cast<hipStream_t>(producer_stream)));
-    HIPOK(hipStreamWaitEvent(h->stream, h->ev_producer, 0));
+    if (static_cast<hipStream_t>(producer_stream) != h->stream) {
+        HIPOK(hipEventRecord(h->ev_producer, static_cast<hipStream_t>(producer_stream)));
+        HIPOK(hipStreamWaitEvent(h->stream, h->ev_producer, 0));
+    }
     for (uint32_t i = 0; i < n; ++i) {
         isccsearch_merge_request& r = reqs[i];
         const size_t rec_bytes = (size_t)r.nq * r.k * sizeof(isk::Record);
@@ -2711,8 +2718,10 @@ int isccsearch_search_device_async(isccsearch_handle* h, uint32_t table, uint32_
                 else batch.self_hint = hint;
             }
             if ((rc = batch.begin(q_words))) return rc;
-            HIPOK(hipEventRecord(h->ev_done, h->stream));
-            HIPOK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->ev_done, 0));
+            if (static_cast<hipStream_t>(consumer_stream) != h->stream) {
+                HIPOK(hipEventRecord(h->ev_done, h->stream));
+                HIPOK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->ev_done, 0));
+            }
             return 0;
         }
     }

@@ -102,6 +102,11 @@ class HipEngine:
             _lib.check(self._lib.isccsearch_merge_device_after(*args, ctypes.c_void_p(after_stream), *outs))
         return out
 
+    def stream(self):
+        # type: () -> int
+        """The library's hipStream_t (``isccsearch_stream``): work a caller queues on it is in order with the library's own."""
+        return int(self._lib.isccsearch_stream(self.handle) or 0)
+
     def merge_many(self, merges, after_stream):
         # type: (list[tuple], int) -> list[tuple]
         """

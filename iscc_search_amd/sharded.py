@@ -13,6 +13,7 @@ second collective: at 160 KB per rank for 1 024 queries the exchange is latency 
 C-ABI); tests drive the same class over gloo with an oracle-backed ops object.
 """
 
+import contextlib
 import os
 
 import numpy as np
@@ -49,6 +50,12 @@ def block_bytes(nq, k):
     return rec, rec + (nq * 4 + 7) // 8 * 8
 
 
+def _exchange_scope(ops):
+    """The ops' scope for one search step (``HipShardOps.exchange_scope``: torch's current stream := the library's), if it has one."""
+    make = getattr(ops, "exchange_scope", None)
+    return make() if make is not None else contextlib.nullcontext()
+
+
 class HipShardOps:
     """Local search + merge on one GPU through the C-ABI; buffers are torch tensors on that GPU."""
 
@@ -61,9 +68,21 @@ class HipShardOps:
         self.device = torch.device(device)
         self.key_words = table.key_words
         self._buffers = {}
+        self._ext = None
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def exchange_scope(self):
+        """
+        torch's current stream := the LIBRARY's stream (``isccsearch_stream`` as a ``torch.cuda.ExternalStream``) for one search
+        step: local search, all-gather (a collective without ``async_op`` is launched on the current stream) and merge are then
+        one in-order queue -- no event between two queues in front of the exchange and in front of the merge (~12 + ~21 us of
+        hand-over per step, ``profiles/r04_step_timelines.txt``).  Outside the scope the calls still order themselves by events.
+        """
+        if self._ext is None:
+            self._ext = self.torch.cuda.ExternalStream(self.engine.stream(), device=self.device)
+        return self.torch.cuda.stream(self._ext)
 
     supports_hint = True
 
@@ -267,75 +286,76 @@ class ShardedTable:
             return None            # (two items on one table with one block size would share that table's block buffer)
         if any(t.world_size != first.world_size or t.group is not first.group for t, *_ in items):
             return None
-        # every item's shards start under the GLOBAL k-th distance its table's previous search of this shape ended at (as `_search`):
-        # the per-unit searches of a request then cost each shard one range-limited pass instead of bootstrap + levels
-        blocks, states = [], []
-        for t, q_words, q_nbytes, k, max_hamming in items:
-            state, how = None, {}
-            if t.use_hints and max_hamming is None:
-                qlen = None if q_nbytes is None else tuple(sorted(set(int(b) for b in np.asarray(q_nbytes))))
-                state = t._hints.setdefault((int(q_words.shape[0]).bit_length(), int(k), qlen), [None, 0, 0])
-                if state[0] is not None and state[1] == 0:
-                    how = {"hint": state[0]}
-                elif state[1]:
-                    state[1] -= 1
-            states.append((state, bool(how)))
-            blocks.append(t.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else t.ops.local_search(q_words, q_nbytes, k, max_hamming))
-        share = torch.cat(blocks)
-        total = share.numel()
-        if share.is_cuda and first.dist.get_backend(first.group) == "gloo":
-            host = torch.empty(first.world_size * total, dtype=share.dtype)      # rehearsal transport: staged through the host
-            first.dist.all_gather_into_tensor(host, share.cpu(), group=first.group)
-            gathered = host.to(share.device)
-        else:
-            make = getattr(first.ops, "buffer", None)
-            gathered = make("gathered", first.world_size * total) if make else torch.empty(first.world_size * total, dtype=share.dtype, device=share.device)
-            first.dist.all_gather_into_tensor(gathered, share, group=first.group)
-        # the merges: queued back to back behind ONE synchronisation when the ops share an engine that can (HipShardOps.merge_many)
-        merged = None
-        many = getattr(first.ops, "merge_many", None)
-        if many is not None and all(getattr(t.ops, "engine", None) is first.ops.engine for t, *_ in items):
-            parts, offset = [], 0
-            for (t, q_words, _, k, _), block in zip(items, blocks):
-                parts.append((offset, t.world_size, q_words.shape[0], k, t.ops.key_words))
-                offset += block.numel()
-            merged = many(gathered, total, parts)
-        out, offset = [], 0
-        for (t, q_words, q_nbytes, k, max_hamming), block in zip(items, blocks):
-            nq = q_words.shape[0]
-            strided = getattr(t.ops, "merge_strided", None)
-            if merged is not None:
-                res = merged[len(out)]
-            elif strided is not None:
-                res = strided(gathered, offset, total, t.world_size, nq, k)
+        with _exchange_scope(first.ops):
+            # every item's shards start under the GLOBAL k-th distance its table's previous search of this shape ended at (as `_search`):
+            # the per-unit searches of a request then cost each shard one range-limited pass instead of bootstrap + levels
+            blocks, states = [], []
+            for t, q_words, q_nbytes, k, max_hamming in items:
+                state, how = None, {}
+                if t.use_hints and max_hamming is None:
+                    qlen = None if q_nbytes is None else tuple(sorted(set(int(b) for b in np.asarray(q_nbytes))))
+                    state = t._hints.setdefault((int(q_words.shape[0]).bit_length(), int(k), qlen), [None, 0, 0])
+                    if state[0] is not None and state[1] == 0:
+                        how = {"hint": state[0]}
+                    elif state[1]:
+                        state[1] -= 1
+                states.append((state, bool(how)))
+                blocks.append(t.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else t.ops.local_search(q_words, q_nbytes, k, max_hamming))
+            share = torch.cat(blocks)
+            total = share.numel()
+            if share.is_cuda and first.dist.get_backend(first.group) == "gloo":
+                host = torch.empty(first.world_size * total, dtype=share.dtype)      # rehearsal transport: staged through the host
+                first.dist.all_gather_into_tensor(host, share.cpu(), group=first.group)
+                gathered = host.to(share.device)
             else:
-                part = gathered.view(t.world_size, total)[:, offset : offset + block.numel()].contiguous().view(-1)
-                res = t.ops.merge(part, t.world_size, nq, k)
-            state, hinted = states[len(out)]
-            cnt = res[3]
-            full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
-            if hinted and not full:
-                # the hint was too tight for some query (or a list overflowed under it): the merged lists are the same on every rank, so
-                # every rank repeats THIS item without it together
-                t.hint_misses += 1
-                state[2] = min(2 * state[2] + 1, 15)
-                state[1] = state[2] - 1
-                res = t._exchange(q_words, q_nbytes, k, max_hamming, {})
-                cnt = res[3]
-                hinted = False
-            if np.any(cnt == COUNT_OVERFLOW):
-                # a shard could only mark an overflowed candidate list: every rank repeats THIS item through the synchronous path together
-                res = t._exchange(q_words, q_nbytes, k, max_hamming, {"synchronous": True})
-                cnt = res[3]
-            if state is not None:
-                full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
-                if hinted:
-                    t.hint_hits += 1
-                    state[0], state[2] = max(int(res[1][:, k - 1].max()) + hint_margin(k), state[0] - 1), 0
+                make = getattr(first.ops, "buffer", None)
+                gathered = make("gathered", first.world_size * total) if make else torch.empty(first.world_size * total, dtype=share.dtype, device=share.device)
+                first.dist.all_gather_into_tensor(gathered, share, group=first.group)
+            # the merges: queued back to back behind ONE synchronisation when the ops share an engine that can (HipShardOps.merge_many)
+            merged = None
+            many = getattr(first.ops, "merge_many", None)
+            if many is not None and all(getattr(t.ops, "engine", None) is first.ops.engine for t, *_ in items):
+                parts, offset = [], 0
+                for (t, q_words, _, k, _), block in zip(items, blocks):
+                    parts.append((offset, t.world_size, q_words.shape[0], k, t.ops.key_words))
+                    offset += block.numel()
+                merged = many(gathered, total, parts)
+            out, offset = [], 0
+            for (t, q_words, q_nbytes, k, max_hamming), block in zip(items, blocks):
+                nq = q_words.shape[0]
+                strided = getattr(t.ops, "merge_strided", None)
+                if merged is not None:
+                    res = merged[len(out)]
+                elif strided is not None:
+                    res = strided(gathered, offset, total, t.world_size, nq, k)
                 else:
-                    state[0] = int(res[1][:, k - 1].max()) + hint_margin(k) if full else None
-            out.append(res)
-            offset += block.numel()
+                    part = gathered.view(t.world_size, total)[:, offset : offset + block.numel()].contiguous().view(-1)
+                    res = t.ops.merge(part, t.world_size, nq, k)
+                state, hinted = states[len(out)]
+                cnt = res[3]
+                full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
+                if hinted and not full:
+                    # the hint was too tight for some query (or a list overflowed under it): the merged lists are the same on every rank, so
+                    # every rank repeats THIS item without it together
+                    t.hint_misses += 1
+                    state[2] = min(2 * state[2] + 1, 15)
+                    state[1] = state[2] - 1
+                    res = t._exchange(q_words, q_nbytes, k, max_hamming, {})
+                    cnt = res[3]
+                    hinted = False
+                if np.any(cnt == COUNT_OVERFLOW):
+                    # a shard could only mark an overflowed candidate list: every rank repeats THIS item through the synchronous path together
+                    res = t._exchange(q_words, q_nbytes, k, max_hamming, {"synchronous": True})
+                    cnt = res[3]
+                if state is not None:
+                    full = not np.any(cnt == COUNT_OVERFLOW) and int(cnt.min()) >= k
+                    if hinted:
+                        t.hint_hits += 1
+                        state[0], state[2] = max(int(res[1][:, k - 1].max()) + hint_margin(k), state[0] - 1), 0
+                    else:
+                        state[0] = int(res[1][:, k - 1].max()) + hint_margin(k) if full else None
+                out.append(res)
+                offset += block.numel()
         return out
 
     def _exchange(self, q_words, q_nbytes, k, max_hamming, how):
@@ -344,19 +364,20 @@ class ShardedTable:
         single = getattr(self.ops, "search_single", None)
         if alone and single is not None:
             return single(q_words, q_nbytes, k, max_hamming)
-        block = self.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else self.ops.local_search(q_words, q_nbytes, k, max_hamming, **how)
-        if alone:
-            return self.ops.merge(block, 1, nq, k)
-        import torch
+        with _exchange_scope(self.ops):
+            block = self.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else self.ops.local_search(q_words, q_nbytes, k, max_hamming, **how)
+            if alone:
+                return self.ops.merge(block, 1, nq, k)
+            import torch
 
-        if block.is_cuda and self.dist.get_backend(self.group) == "gloo":
-            # rehearsal transport (several ranks sharing one GPU cannot use RCCL): stage the blocks through the host
-            host = torch.empty(self.world_size * block.numel(), dtype=block.dtype)
-            self.dist.all_gather_into_tensor(host, block.cpu(), group=self.group)
-            gathered = host.to(block.device)
-        else:
-            make = getattr(self.ops, "buffer", None)
-            gathered = make("gathered", self.world_size * block.numel()) if make else torch.empty(self.world_size * block.numel(), dtype=block.dtype, device=block.device)
-            # the one exchange step of the path: [world] x {records [nq][k] | counts [nq]}
-            self.dist.all_gather_into_tensor(gathered, block, group=self.group)
-        return self.ops.merge(gathered, self.world_size, nq, k)
+            if block.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # rehearsal transport (several ranks sharing one GPU cannot use RCCL): stage the blocks through the host
+                host = torch.empty(self.world_size * block.numel(), dtype=block.dtype)
+                self.dist.all_gather_into_tensor(host, block.cpu(), group=self.group)
+                gathered = host.to(block.device)
+            else:
+                make = getattr(self.ops, "buffer", None)
+                gathered = make("gathered", self.world_size * block.numel()) if make else torch.empty(self.world_size * block.numel(), dtype=block.dtype, device=block.device)
+                # the one exchange step of the path: [world] x {records [nq][k] | counts [nq]}
+                self.dist.all_gather_into_tensor(gathered, block, group=self.group)
+            return self.ops.merge(gathered, self.world_size, nq, k)

@@ -7,10 +7,18 @@
  * number of rows generated on the device by isccsearch_add_synthetic with another seed.  Queries: query j is row (7919 j mod rows)
  * with its lowest j mod 5 bits flipped.  Prints, per query: "q <j> <count> : <key>:<hamming> ..." and, for the range-limited
  * search with max_hamming = 2, "w <j> <count> : ...".
+ *
+ *   abi_client simprint <assets> <chunks> <queries> <limit>
+ * A table with 128-bit keys (asset a = 1 .. assets, chunk c: key = (a, (10 c) << 32 | 10 + c)) of 64-bit simprints drawn from a
+ * pool of 50 -- simprint(a, c) = pool(h mod 50) with (h >> 32) mod 4 bits flipped from bit (h >> 40) mod 60 on, h =
+ * splitmix64(77 + 131 a + c), pool(i) = splitmix64(0x51 + i) -- and one isccsearch_simprint_score call for the query simprints
+ * pool(j mod 50) with their lowest j mod 3 bits flipped (count = 4 limit, threshold 0.8, total_assets = assets, dup_limit 1000).
+ * Prints per result "r <asset> <score %.17g> <matches> : <query>:<key_lo>:<hamming>:<freq>:<stored word> ...".
  */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "isccsearch.h"
 
@@ -27,7 +35,50 @@ static uint64_t splitmix64(uint64_t x) {
         if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, isccsearch_last_error()); return 2; } \
     } while (0)
 
+static int simprint_mode(int argc, char** argv) {
+    const uint64_t assets = argc > 2 ? strtoull(argv[2], NULL, 10) : 300;
+    const uint64_t chunks = argc > 3 ? strtoull(argv[3], NULL, 10) : 6;
+    const uint32_t nq = argc > 4 ? (uint32_t)atoi(argv[4]) : 20;
+    const uint32_t limit = argc > 5 ? (uint32_t)atoi(argv[5]) : 10;
+    const uint64_t n = assets * chunks;
+
+    isccsearch_handle* h = NULL;
+    CHECK(isccsearch_create(0, &h));
+    uint32_t table = 0;
+    CHECK(isccsearch_table_open(h, ISCCSEARCH_METRIC_HAMMING, 2, 8, &table));
+    uint64_t* keys = malloc(2 * n * sizeof *keys);
+    uint64_t* words = malloc(n * sizeof *words);
+    for (uint64_t a = 1, i = 0; a <= assets; ++a)
+        for (uint64_t c = 0; c < chunks; ++c, ++i) {
+            const uint64_t hh = splitmix64(77 + 131 * a + c);
+            keys[2 * i] = a;
+            keys[2 * i + 1] = ((10 * c) << 32) | (10 + c);
+            words[i] = splitmix64(0x51 + hh % 50) ^ ((((uint64_t)1 << ((hh >> 32) % 4)) - 1) << ((hh >> 40) % 60));
+        }
+    CHECK(isccsearch_add(h, table, n, keys, words, NULL, 0));
+
+    uint64_t* q = malloc(nq * sizeof *q);
+    for (uint32_t j = 0; j < nq; ++j) q[j] = splitmix64(0x51 + j % 50) ^ (((uint64_t)1 << (j % 3)) - 1);
+    isccsearch_simprint_result* res = malloc(limit * sizeof *res);
+    isccsearch_simprint_chunk* ch = malloc((size_t)limit * nq * sizeof *ch);
+    uint64_t* cw = malloc((size_t)limit * nq * sizeof *cw);
+    uint32_t info[4] = {0, 0, 0, 0};
+    CHECK(isccsearch_simprint_score(h, table, nq, q, 4 * limit, -1, 0.8, limit, (int64_t)assets, 1000, res, ch, cw, info));
+    printf("info %u %u %u %u\n", info[0], info[1], info[2], info[3]);
+    for (uint32_t r = 0; r < info[0]; ++r) {
+        printf("r %llu %.17g %u :", (unsigned long long)res[r].asset, res[r].score, res[r].matches);
+        for (uint32_t i = res[r].first_chunk; i < res[r].first_chunk + res[r].matches; ++i)
+            printf(" %u:%llu:%u:%u:%llu", ch[i].query, (unsigned long long)ch[i].key_lo, ch[i].hamming, ch[i].freq, (unsigned long long)cw[i]);
+        printf("\n");
+    }
+    CHECK(isccsearch_table_drop(h, table));
+    CHECK(isccsearch_destroy(h));
+    free(keys); free(words); free(q); free(res); free(ch); free(cw);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && strcmp(argv[1], "simprint") == 0) return simprint_mode(argc, argv);
     const uint64_t n = argc > 1 ? strtoull(argv[1], NULL, 10) : 100000;
     const uint32_t nq = argc > 2 ? (uint32_t)atoi(argv[2]) : 8;
     const uint32_t k = argc > 3 ? (uint32_t)atoi(argv[3]) : 5;
