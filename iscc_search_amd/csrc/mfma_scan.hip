@@ -558,9 +558,28 @@ __device__ __forceinline__ uint32_t live_packed(const float* addr) {
     return (uint32_t)__hip_atomic_load(reinterpret_cast<const int*>(addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ISK_EXP_PACK (experiment switch, never in the product build; tools/pack_step_accounting.sh): what the parts of a step cost, by
+// leaving them out -- results are WRONG, only the launch time and the counters of the kernel mean anything.
+//   bit 0: no fold (the 16 v_pk_minimum3_f16 + v_cmp of a stage: no row is ever a candidate)
+//   bit 1: the rows are loaded but expanded only once, before the loop
+//   bit 2: no looks (threshold refresh, checkers)
+//   bit 3: see ISK_MF2
+#ifndef ISK_EXP_PACK
+#define ISK_EXP_PACK 0
+#endif
+#if ISK_EXP_PACK & 1
+#define ISK_PKM "; v_pk_minimum3_f16 "
+#define ISK_CMP "s_mov_b64 %[mask], 0\n"
+#else
 #define ISK_PKM "v_pk_minimum3_f16 "
+#define ISK_CMP "v_cmp_ne_u32_e64 %[mask], %[t], %[mA]\n"
+#endif
 #define ISK_MF1(n, av) "v_mfma_f32_32x32x64_f8f6f4 %[" #n "], %[" #av "], %[b], %[mg] cbsz:4 blgp:4\n"
+#if ISK_EXP_PACK & 8       // bit 3: the second tile of an accumulator multiplied WITHOUT its block scale (no v_mfma_ld_scale_b32 prefix)
+#define ISK_MF2(n, av) "v_mfma_f32_32x32x64_f8f6f4 %[" #n "], %[" #av "], %[b], %[" #n "] cbsz:4 blgp:4\n"
+#else
 #define ISK_MF2(n, av) "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #n "], %[" #av "], %[b], %[" #n "], %[sh], %[so] op_sel_hi:[0,0,0] cbsz:4 blgp:4\n"
+#endif
 
 // DEPTH: steps whose rows a wave keeps in flight.  A chunk of 32 groups works ~5 000 cycles on a step's 1 KB of rows and one
 // step ahead hides any latency; a chunk of one or two groups is done in ~400, and with one step (3 waves x 4 SIMDs x 1 KB =
@@ -747,7 +766,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                      "s_nop 0\n"
                      ISK_PKM "%[mA], %[mA], %[mB], %[w15]\n"
                      "s_nop 0\n"
-                     "v_cmp_ne_u32_e64 %[mask], %[t], %[mA]\n"
+                     ISK_CMP
                      : [n1] "+v"(nw.t[1]), [mA] "+v"(mA), [mB] "+v"(mB), [mask] "=s"(mask)
                      : [a3] "v"(a[3]), [b] "v"(b), [sh] "v"(sc_hi), [so] "v"(sc_one), [t] "v"(tpk), [w4] "v"(o1[4]), [w5] "v"(o1[5]), [w6] "v"(o1[6]), [w7] "v"(o1[7]),
                        [w13] "v"(o1[13]), [w14] "v"(o1[14]), [w15] "v"(o1[15]));
@@ -782,7 +801,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                      "s_nop 0\n"
                      ISK_PKM "%[mA], %[mA], %[mB], %[w15]\n"
                      "s_nop 0\n"
-                     "v_cmp_ne_u32_e64 %[mask], %[t], %[mA]\n"
+                     ISK_CMP
                      : [mA] "+v"(mA), [mB] "+v"(mB), [mask] "=s"(mask)
                      : [t] "v"(tpk), [u15] "v"(o0[15]), [w0] "v"(o1[0]), [w1] "v"(o1[1]), [w2] "v"(o1[2]), [w3] "v"(o1[3]), [w4] "v"(o1[4]), [w5] "v"(o1[5]), [w6] "v"(o1[6]),
                        [w7] "v"(o1[7]), [w8] "v"(o1[8]), [w9] "v"(o1[9]), [w10] "v"(o1[10]), [w11] "v"(o1[11]), [w12] "v"(o1[12]), [w13] "v"(o1[13]), [w14] "v"(o1[14]), [w15] "v"(o1[15]));
@@ -963,7 +982,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     // one step over the rows expanded in a[]: `body` multiplies and folds
     auto one_step = [&](auto&& body) __attribute__((always_inline)) {
         uint32_t fresh[4] = {0u, 0u, 0u, 0u};
-        const bool look = trip < 4 || (trip & refresh_mask) == 0;
+        const bool look = !(ISK_EXP_PACK & 4) && (trip < 4 || (trip & refresh_mask) == 0);
         const bool refresh_now = refresh && look;
         uint32_t chk_count = 0, chk_what = ~0u;       // chk_what: query in chunk | hamming level << 16, ~0: no task
         if constexpr (MODE == MODE_SELF) {
@@ -1008,8 +1027,10 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
                 ++trip;
             }
         } else {
+            if (ISK_EXP_PACK & 2) expand(x);
             while (step < nsteps) {
-                expand(x);
+                if (ISK_EXP_PACK & 2) asm volatile("" ::"v"(x));
+                else expand(x);
                 x = load_rows(step + stride < nsteps ? step + stride : step);
                 one_step([&]() __attribute__((always_inline)) { even_groups(step - stride); });
                 step += stride;
