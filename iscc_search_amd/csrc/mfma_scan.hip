@@ -817,7 +817,7 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
     // lanes >= 32 received y of lane m) and rows 2 m + 64 -- and swap(z, w) the tiles of rows 2 m + 1 and 2 m + 65.  Before:
     // four 4-byte loads per lane and step, four times the address work of the texture path for the same bytes.
     auto load_rows = [&](uint64_t st) __attribute__((always_inline)) -> u32x4 {          // compiler-scheduled: DEPTH == 1, and the table's partial last step
-        if ((st + 1) * (32 * MT) <= p.n_rows) return reinterpret_cast<const u32x4*>(col32 + st * (64 * MT))[lane];
+        if ((st + 1) * (32 * MT) <= p.n_rows) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(col32 + st * (64 * MT)) + lane);
         const uint64_t r0 = st * (32 * MT) + 2 * lane, r1 = r0 + 1;
         const uint2 lo = *reinterpret_cast<const uint2*>(col32 + (r0 <= last_row ? r0 : last_row) * 2);
         const uint2 hi = *reinterpret_cast<const uint2*>(col32 + (r1 <= last_row ? r1 : last_row) * 2);
@@ -844,7 +844,9 @@ __global__ __launch_bounds__(MBLOCK, 3) void mfma_pack_kernel(const ScanParams p
             ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr));
         // ("+v": a slot is ONE register quadruple for the whole kernel, updated in place -- as a fresh output per load, hipcc gave
         //  some instantiations' slots different registers in the loop and rotated them with copies at the back edge, in flight)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2\n\t" : "+v"(dst) : "v"(lane_bytes), "s"(base) : "memory");
+        // (`nt`: the rows are read once -- 9..32 queries scanned at 5.2 TB/s without the hint, 5.8 with it: 0.153 -> 0.139 ms per 100 M rows,
+        //  profiles/r04_pmc_sq_small_chunks.txt; the XOR + popcount kernel's loads carry it too)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt\n\t" : "+v"(dst) : "v"(lane_bytes), "s"(base) : "memory");
     };
     auto await_rows = [&](u32x4& v) __attribute__((always_inline)) {                     // DEPTH - 1 younger row loads are outstanding at every wait
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
