@@ -365,3 +365,35 @@ def test_hard_boundary_search_with_more_lookups_than_one_batch(engine):
     for g, w in zip(got, want):
         assert [(c.query, c.offset, c.size, c.freq) for c in g.chunks] == [(c.query, c.offset, c.size, c.freq) for c in w.chunks]
     index.close()
+
+
+def test_the_largest_request_the_library_takes(engine):
+    """
+    8 192 query simprints (``ISCCSEARCH_MAX_SCORED_SIMPRINTS``) x limit 204 = 4 080 neighbours each (33 M records, none of them
+    leaving the device) and a limit whose oversampled count exceeds ``MAX_K`` (radius lists): the device scoring against the host
+    scoring of the same neighbour lists -- same assets, ``==`` scores, same chunks (``tools/probe_score_extremes.py`` at 1 M rows).
+    """
+    rng = np.random.default_rng(5)
+    rows = 200_000
+    pool = [rng.integers(0, 256, size=16, dtype=np.uint8).tobytes() for _ in range(4000)]
+    keys, vecs = [], []
+    for i in range(rows):
+        a, c = divmod(i, 20)
+        keys.append(pack_chunk_pointer((a + 1).to_bytes(8, "big"), c * 7, 7))
+        v = flip_bits(pool[int(rng.integers(0, len(pool)))], int(rng.integers(0, 6))) if i % 3 == 0 else rng.integers(0, 256, size=16, dtype=np.uint8).tobytes()
+        vecs.append(np.frombuffer(v, dtype=np.uint8))
+    index = HipSimprintIndex(engine, ndim=128)
+    index.add_raw(keys, vecs)
+    for nq, limit in ((8192, 204), (100, 300)):
+        simprints = [flip_bits(pool[i % len(pool)], i % 5) for i in range(nq)]
+        for device_doc_freq in (True, False):
+            got = index.search_raw(simprints, limit=limit, threshold=0.9, detailed=True, total_assets=rows // 20, device_doc_freq=device_doc_freq)
+            want = index._search_raw_host(simprints, limit, 0.9, True, None, rows // 20, device_doc_freq)
+            assert len(got) == len(want) == limit
+            for x, y in zip(got, want):
+                assert (x.iscc_id_body, x.score, x.matches, x.queried) == (y.iscc_id_body, y.score, y.matches, y.queried)
+                assert [(c.query, c.match, c.score, c.offset, c.size, c.freq) for c in x.chunks] == [(c.query, c.match, c.score, c.offset, c.size, c.freq) for c in y.chunks]
+    # one more simprint than the library scores in one call: refused there (search_raw itself takes the host path for such requests)
+    with pytest.raises((ValueError, RuntimeError, OSError)):
+        index._search_raw_device([pool[0]] * 8193, 1, 0.9, False, 10, 1000)
+    index.close()
