@@ -56,6 +56,28 @@ def _exchange_scope(ops):
     return make() if make is not None else contextlib.nullcontext()
 
 
+class _OnLibraryStream:
+    """``with``: the calling thread's current torch stream on the ops' device is the library's stream; restored on the way out."""
+
+    __slots__ = ("ops", "prev")
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.prev = None
+
+    def __enter__(self):
+        ops = self.ops
+        if ops._stream() != ops._lib_stream:
+            self.prev = ops._get_current(ops._device_index)           # (stream id, device index, device type)
+            ops._set_current(stream_id=ops._ext.stream_id, device_index=ops._ext.device_index, device_type=ops._ext.device_type)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            self.ops._set_current(stream_id=self.prev[0], device_index=self.prev[1], device_type=self.prev[2])
+        return False
+
+
 class HipShardOps:
     """Local search + merge on one GPU through the C-ABI; buffers are torch tensors on that GPU."""
 
@@ -69,8 +91,16 @@ class HipShardOps:
         self.key_words = table.key_words
         self._buffers = {}
         self._ext = None
+        self._lib_stream = self.engine.stream() if hasattr(self.engine, "stream") else 0
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._get_current = getattr(torch._C, "_cuda_getCurrentStream", None)
+        self._set_current = getattr(torch._C, "_cuda_setStream", None)
+        self._device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     def _stream(self):
+        # (torch.cuda.current_stream() builds a Stream object: 5.5 us a call, three calls a step; the raw accessor returns the pointer)
+        if self._raw_stream is not None:
+            return self._raw_stream(self._device_index)
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
     def exchange_scope(self):
@@ -79,10 +109,13 @@ class HipShardOps:
         step: local search, all-gather (a collective without ``async_op`` is launched on the current stream) and merge are then
         one in-order queue -- no event between two queues in front of the exchange and in front of the merge (~12 + ~21 us of
         hand-over per step, ``profiles/r04_step_timelines.txt``).  Outside the scope the calls still order themselves by events.
+        (``torch.cuda.stream()`` does the same in ~10 us of Stream objects a step; with torch's raw accessors it is ~2.)
         """
         if self._ext is None:
-            self._ext = self.torch.cuda.ExternalStream(self.engine.stream(), device=self.device)
-        return self.torch.cuda.stream(self._ext)
+            self._ext = self.torch.cuda.ExternalStream(self._lib_stream, device=self.device)
+        if self._raw_stream is None or self._get_current is None or self._set_current is None:
+            return self.torch.cuda.stream(self._ext)
+        return _OnLibraryStream(self)
 
     supports_hint = True
 
@@ -177,6 +210,13 @@ class ShardedTable:
         self.use_hints = bool(getattr(ops, "supports_hint", False)) and not os.environ.get("ISCC_NO_SHARD_HINT")
         self._hints = {}
         self.hint_hits = self.hint_misses = 0
+        self._stages_on_host = None
+
+    def _staged(self):
+        """The rehearsal transport (several ranks sharing one GPU cannot use RCCL: gloo, blocks staged through the host)?  Asked once."""
+        if self._stages_on_host is None:
+            self._stages_on_host = self.dist.get_backend(self.group) == "gloo"
+        return self._stages_on_host
 
     def search(self, q_words, q_nbytes, k):
         # type: (np.ndarray, np.ndarray | None, int) -> tuple
@@ -303,7 +343,7 @@ class ShardedTable:
                 blocks.append(t.ops.local_search(q_words, q_nbytes, k, **how) if max_hamming is None else t.ops.local_search(q_words, q_nbytes, k, max_hamming))
             share = torch.cat(blocks)
             total = share.numel()
-            if share.is_cuda and first.dist.get_backend(first.group) == "gloo":
+            if share.is_cuda and first._staged():
                 host = torch.empty(first.world_size * total, dtype=share.dtype)      # rehearsal transport: staged through the host
                 first.dist.all_gather_into_tensor(host, share.cpu(), group=first.group)
                 gathered = host.to(share.device)
@@ -370,7 +410,7 @@ class ShardedTable:
                 return self.ops.merge(block, 1, nq, k)
             import torch
 
-            if block.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            if block.is_cuda and self._staged():
                 # rehearsal transport (several ranks sharing one GPU cannot use RCCL): stage the blocks through the host
                 host = torch.empty(self.world_size * block.numel(), dtype=block.dtype)
                 self.dist.all_gather_into_tensor(host, block.cpu(), group=self.group)
