@@ -132,7 +132,10 @@ const char* isccsearch_last_error(void);
  * "mfma_stretch_factor" (3) times that), "fold_tau" (whole 64-bit codes: query groups whose
  * thresholds are all <= this take the folded 3.5-op fast path; default 11, 0 = never); tuning: "blocks_per_cu", "boot_rows",
  * "level_growth", "repick"; "count_candidates" (0|1: after every batch read back how many candidates its scan appended --
- * statistics `candidates` / `candidate_batches`; one more copy and synchronisation per batch, for accounting runs).
+ * statistics `candidates` / `candidate_batches`; one more copy and synchronisation per batch, for accounting runs);
+ * "select_wide_from" (2 048: selects whose LDS sort buffer has at least this many slots -- k > 256 -- run 1 024-thread blocks
+ * instead of 256-thread ones when the batch has fewer queries than half the CUs, and whatever the batch from twice that many
+ * slots; a larger value than any buffer turns that off).
  * "nontemporal" accepts only 1 (the only variant built). */
 int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value);
 int isccsearch_stats_get(isccsearch_handle* h, isccsearch_stats* out, int reset);

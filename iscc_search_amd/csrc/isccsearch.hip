@@ -204,6 +204,7 @@ struct isccsearch_handle {
                                    // (100 M x 64-bit: 8 queries 0.231 against 0.252 ms, 4 queries at k = 100 0.286 against 0.354)
     uint64_t level_growth = 8;     // each threshold level streams this many times the rows seen so far
     bool repick = true;            // re-derive the threshold after every collect stretch but the last
+    uint32_t select_wide_from = 2048; // sort buffers of at least this many slots are selected by 1 024-thread blocks (option; 0xFFFFFFFF: never)
     uint32_t fold_tau = 11;        // 64-bit codes: groups whose thresholds are all <= this take the folded fast path (0: off)
     uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
     uint64_t mfma_stretch_factor = 3;               // ... times this on the matrix cores, when several CHUNKS of queries share them
@@ -553,12 +554,22 @@ struct Batch {
         c.sl.out_kth = multi ? nullptr : d_out_kth;
         return c;
     }
-    void launch_select(const isk::SelectParams& sl, uint32_t blocks) const {
+    template <int NT>
+    void launch_select_nt(const isk::SelectParams& sl, uint32_t blocks) const {
         if (sl.out_rows) {
-            if (t.key_words == 2) hipLaunchKernelGGL((isk::select_kernel<2, true>), dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
-            else hipLaunchKernelGGL((isk::select_kernel<1, true>), dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
-        } else if (t.key_words == 2) hipLaunchKernelGGL(isk::select_kernel<2>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
-        else hipLaunchKernelGGL(isk::select_kernel<1>, dim3(blocks), dim3(isk::BLOCK), sel_lds, h->stream, sl);
+            if (t.key_words == 2) hipLaunchKernelGGL((isk::select_kernel<2, true, NT>), dim3(blocks), dim3(NT), sel_lds, h->stream, sl);
+            else hipLaunchKernelGGL((isk::select_kernel<1, true, NT>), dim3(blocks), dim3(NT), sel_lds, h->stream, sl);
+        } else if (t.key_words == 2) hipLaunchKernelGGL((isk::select_kernel<2, false, NT>), dim3(blocks), dim3(NT), sel_lds, h->stream, sl);
+        else hipLaunchKernelGGL((isk::select_kernel<1, false, NT>), dim3(blocks), dim3(NT), sel_lds, h->stream, sl);
+    }
+    // A large sort buffer leaves room for one or two blocks per CU (LDS): with 256 threads those are 4 - 8 waves walking ~60 bitonic stages
+    // and two rounds of dependent gathers.  1 024-thread blocks when the launch cannot fill the chip with blocks anyway (fewer queries
+    // than half the CUs: 10 M x 128-bit, 16 queries, k = 400: 0.148 -> 0.138 ms per call) and for the largest buffers (k = 2 000 over
+    // 100 M rows x 1 024 queries: 6.06 -> 5.4 - 5.6 ms); many queries at k = 400 are no faster that way (0.59 -> 0.61 - 0.63 ms), they keep 256.
+    void launch_select(const isk::SelectParams& sl, uint32_t blocks) const {
+        const bool wide = sl.P >= h->select_wide_from && (sl.P >= 2 * h->select_wide_from || blocks <= (uint32_t)h->cus / 2);
+        if (wide) launch_select_nt<1024>(sl, blocks);
+        else launch_select_nt<isk::BLOCK>(sl, blocks);
     }
     size_t flag_words() const { return jobs.size() * (size_t)nq_pad; }
 
@@ -1231,6 +1242,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_pack")) { h->mfma_pack = value != 0; return 0; }
+    if (!strcmp(name, "select_wide_from")) { if (value < 0) return fail(-EINVAL, "select_wide_from must be >= 0"); h->select_wide_from = (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll); return 0; }
     if (!strcmp(name, "speculate")) { h->speculate = value != 0; return 0; }
     if (!strcmp(name, "spec_max_queries")) { if (value < 0 || value > 1024) return fail(-EINVAL, "spec_max_queries must be 0..1024"); h->spec_max_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_boot_per_k")) { if (value < 0 || value > (1 << 20)) return fail(-EINVAL, "self_boot_per_k must be 0..2^20"); h->self_boot_per_k = (uint32_t)value; return 0; }
