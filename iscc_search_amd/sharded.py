@@ -111,6 +111,8 @@ class HipShardOps:
         hand-over per step, ``profiles/r04_step_timelines.txt``).  Outside the scope the calls still order themselves by events.
         (``torch.cuda.stream()`` does the same in ~10 us of Stream objects a step; with torch's raw accessors it is ~2.)
         """
+        if not self._lib_stream or os.environ.get("ISCC_HIP_SHARD_ONE_QUEUE", "1") == "0":
+            return contextlib.nullcontext()              # the step's stages on torch's own current stream, ordered by events
         if self._ext is None:
             self._ext = self.torch.cuda.ExternalStream(self._lib_stream, device=self.device)
         if self._raw_stream is None or self._get_current is None or self._set_current is None:

@@ -78,12 +78,16 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c1["add_assets_per_s"] > 0 and c1["search_assets_per_s"] > 0
 
 
-def test_a_one_rank_collective_run_reports_what_the_communicator_saw():
+@pytest.mark.parametrize("one_queue", ["1", "0"])
+def test_a_one_rank_collective_run_reports_what_the_communicator_saw(one_queue):
+    """... with the step's search, all-gather and merge on the library's stream (default) and on torch's own stream, ordered by events:
+    bench.py gates every batch (planted neighbour first, sorted, full) and compares every batch's last answer with its gate answer."""
     proc = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "2000000", "--steps", "3", "--warmup", "1", "--force-collective",
          "--no-cpu-baseline", "--no-extra-legs"],
-        capture_output=True, text=True, timeout=600, cwd=ROOT,
+        capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, ISCC_HIP_SHARD_ONE_QUEUE=one_queue),
     )
     assert proc.returncode == 0, proc.stderr[-2000:]
     out = json.loads([l for l in proc.stdout.splitlines() if l.strip()][-1])
     assert out["world_size_seen"] == 1 and out["collective_backend"] == "nccl" and out["rccl_version"]
+    assert out["batches_gated"] == 8 and len(out["batches_compared_after_measurement"]) >= 3      # three measured steps (and what the other legs rotated through)
