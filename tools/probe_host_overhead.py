@@ -26,13 +26,12 @@ t0 = time.perf_counter()
 for _ in range(N):
     t.search(q, None, k)
 whole = (time.perf_counter() - t0) / N
-out = _alloc_out(nq, k, 1)
+out, addr = _alloc_out(nq, k, 1)
 qn = t._nbytes(None, nq)
 qw = t._words(q)
 t0 = time.perf_counter()
 for _ in range(N):
-    eng._lib.isccsearch_search(eng.handle, t.id, nq, _lib.ptr(qw, ctypes.c_uint64), _lib.ptr(qn, ctypes.c_uint8), k,
-                               _lib.ptr(out[0], ctypes.c_uint64), _lib.ptr(out[1], ctypes.c_uint32), _lib.ptr(out[2], ctypes.c_uint16), _lib.ptr(out[3], ctypes.c_uint32))
+    eng._lib.isccsearch_search(eng.handle, t.id, nq, _lib.ptr(qw), _lib.ptr(qn), k, *addr)
 ccall = (time.perf_counter() - t0) / N
 eng.stats(reset=True)
 eng.set_option("profile", 1)
