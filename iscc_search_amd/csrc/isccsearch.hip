@@ -446,7 +446,9 @@ uint32_t scan_grid_x(H* h, int W, uint64_t rows, uint32_t groups = 1, bool sampl
     uint64_t maxb = (uint64_t)h->cus * h->blocks_per_cu;
     if (sample || rows * 8 * (uint64_t)W <= CACHE_RESIDENT_BYTES)
         maxb = std::max<uint64_t>(8, maxb / std::max<uint32_t>(1, groups));
-    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, maxb));
+    // (the rows behind the last whole tile are scanned one slice of BLOCK rows per block: at least that many blocks)
+    const uint64_t tail_slices = (rows % (uint64_t)tile_rows_for(W) + isk::BLOCK - 1) / isk::BLOCK;
+    return (uint32_t)std::max<uint64_t>(std::max<uint64_t>(1, tail_slices), std::min<uint64_t>(tiles, maxb));
 }
 
 int drain_events(H* h);

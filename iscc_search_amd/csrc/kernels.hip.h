@@ -396,27 +396,31 @@ __device__ __forceinline__ void scan_body(const ScanParams& p) {
         }
     }
 
-    // tail rows [n_full*TILE, n_rows): one row per thread, handled by the first block of the group
-    if (blockIdx.x == 0) {
-        for (uint64_t row = (uint64_t)n_full * TILE + tid; row < p.n_rows; row += BLOCK) {
+    // tail rows [n_full*TILE, n_rows): one row per thread, a slice of 256 rows per block (the host launches at least as many blocks
+    // as the tail has slices).  One block used to walk the whole tail, up to 8 rounds of dependent loads: a one-query scan of 10 000
+    // rows took 15 us, of 1 M rows 9 -- most of it this loop.
+    {
+        for (uint64_t row = (uint64_t)n_full * TILE + (uint64_t)blockIdx.x * BLOCK + tid; row < p.n_rows; row += (uint64_t)gridDim.x * BLOCK) {
             uint32_t lo[W], hi[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const uint64_t c = p.col[w][row];
                 lo[w] = (uint32_t)c; hi[w] = (uint32_t)(c >> 32);
             }
-#pragma unroll 1
+            // (queries and biases as the tiles take them -- SGPRs or LDS, loaded in the prologue: re-read from global memory per query,
+            //  a slice cost TQ rounds of dependent scalar loads)
+#pragma unroll
             for (int q = 0; q < TQ; ++q) {
-                const uint32_t b = p.bias[q0 + q];
-                uint32_t a = b;
+                uint32_t ql[W], qh[W];
+                query_words(q, ql, qh);
+                uint32_t a = bias[q];
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    const uint64_t qq = p.queries[(uint64_t)(q0 + q) * 4 + w];
-                    uint32_t x = lo[w] ^ (uint32_t)qq, y = hi[w] ^ (uint32_t)(qq >> 32);
+                    uint32_t x = lo[w] ^ ql[w], y = hi[w] ^ qh[w];
                     if (MASK && w == W - 1) { x &= mlo; y &= mhi; }
                     a = bcnt(y, bcnt(x, a));
                 }
-                if ((int32_t)a >= 0) emit<MODE>(p, q0 + q, a - b, row);
+                if ((int32_t)a >= 0) emit<MODE>(p, q0 + q, a - bias[q], row);
             }
         }
     }
