@@ -133,6 +133,8 @@ const char* isccsearch_last_error(void);
  * thresholds are all <= this take the folded 3.5-op fast path; default 11, 0 = never); tuning: "blocks_per_cu", "boot_rows",
  * "level_growth", "repick"; "count_candidates" (0|1: after every batch read back how many candidates its scan appended --
  * statistics `candidates` / `candidate_batches`; one more copy and synchronisation per batch, for accounting runs);
+ * "tiny_rows" (16 384: a segment of at most this many rows is answered by ONE launch, one block per query -- distances of every row,
+ * candidate list, select; 0: never.  Tables the caller sends to the matrix cores by lowering "mfma_min_rows" keep that path);
  * "select_wide_from" (2 048: selects whose LDS sort buffer has at least this many slots -- k > 256 -- run 1 024-thread blocks
  * instead of 256-thread ones when the batch has fewer queries than half the CUs, and whatever the batch from twice that many
  * slots; a larger value than any buffer turns that off).

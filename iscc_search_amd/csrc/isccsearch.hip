@@ -204,6 +204,7 @@ struct isccsearch_handle {
                                    // (100 M x 64-bit: 8 queries 0.231 against 0.252 ms, 4 queries at k = 100 0.286 against 0.354)
     uint64_t level_growth = 8;     // each threshold level streams this many times the rows seen so far
     bool repick = true;            // re-derive the threshold after every collect stretch but the last
+    uint32_t tiny_rows = 16384;       // segments of at most this many rows are answered by ONE launch (tiny_search_kernel); 0: never
     uint32_t select_wide_from = 2048; // sort buffers of at least this many slots are selected by 1 024-thread blocks (option; 0xFFFFFFFF: never)
     uint32_t fold_tau = 11;        // 64-bit codes: groups whose thresholds are all <= this take the folded fast path (0: off)
     uint64_t stretch_bytes = CACHE_STRETCH_BYTES;   // rows per collect launch when several query groups share them (0: one pass)
@@ -573,6 +574,16 @@ struct Batch {
         if (wide) launch_select_nt<1024>(sl, blocks);
         else launch_select_nt<isk::BLOCK>(sl, blocks);
     }
+    // (a caller that sends small tables to the matrix cores -- mfma_min_rows lowered: the parity tests of those kernels -- gets them)
+    bool tiny(const Job& j) const { return h->tiny_rows && j.seg->n <= h->tiny_rows && j.seg->n <= cap && j.seg->n < h->mfma_min_rows; }
+    template <int NT>
+    void launch_tiny_nt(const isk::TinyParams& tp, const isk::SelectParams& sl, const isk::InlineQueries& iq) const {
+        if (sl.out_rows) {
+            if (t.key_words == 2) hipLaunchKernelGGL((isk::tiny_search_kernel<2, true, NT>), dim3(nq), dim3(NT), sel_lds, h->stream, tp, sl, iq);
+            else hipLaunchKernelGGL((isk::tiny_search_kernel<1, true, NT>), dim3(nq), dim3(NT), sel_lds, h->stream, tp, sl, iq);
+        } else if (t.key_words == 2) hipLaunchKernelGGL((isk::tiny_search_kernel<2, false, NT>), dim3(nq), dim3(NT), sel_lds, h->stream, tp, sl, iq);
+        else hipLaunchKernelGGL((isk::tiny_search_kernel<1, false, NT>), dim3(nq), dim3(NT), sel_lds, h->stream, tp, sl, iq);
+    }
     size_t flag_words() const { return jobs.size() * (size_t)nq_pad; }
 
     // One scan launch over rows [sp.row_begin, sp.n_rows) for all query groups.  Large batches over enough rows go to
@@ -672,8 +683,12 @@ struct Batch {
             for (int w = 0; w < t.max_words; ++w) pq[(size_t)q * 4 + w] = hq[(size_t)q * t.max_words + w];
         // (a range-limited search of <= 16 queries over one segment -- the speculative single pass of search_locked -- carries its
         //  queries in the ARGUMENTS of its first kernel, which writes them to d_queries: one stream operation less, ~8 us of 170)
-        const bool inline_queries = radius >= 0 && nq_pad <= isk::INLINE_QUERIES && jobs.size() == 1;
-        if (!inline_queries) HIPOK(hipMemcpyAsync(h->d_queries.p, pq, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
+        // (... and so do the one-launch searches of tiny segments: when every job of the batch is one, nothing is uploaded at all)
+        bool all_tiny = true;
+        for (const Job& j : jobs) all_tiny = all_tiny && tiny(j);
+        const bool tiny_inline = all_tiny && nq_pad <= isk::INLINE_QUERIES;
+        const bool inline_queries = !all_tiny && radius >= 0 && nq_pad <= isk::INLINE_QUERIES && jobs.size() == 1;
+        if (!inline_queries && !tiny_inline) HIPOK(hipMemcpyAsync(h->d_queries.p, pq, (size_t)nq_pad * 4 * 8, hipMemcpyHostToDevice, h->stream));
         if (mark_overflow) { HIPOK(hipEventRecord(h->ev_staged, h->stream)); h->ev_staged_pending = true; }
 
         for (size_t ji = 0; ji < jobs.size(); ++ji) {
@@ -682,6 +697,30 @@ struct Batch {
             Ctx c = make_ctx(ji);
             isk::ScanParams& sp = c.sp;
             const int jr = job_radius(j);
+
+            if (tiny(j)) {
+                // ONE launch: distances of every row, candidate list, select -- exact, nothing to verify or to repeat
+                isk::TinyParams tp{};
+                for (uint32_t w = 0; w < j.W; ++w) tp.col[w] = s.col[w];
+                tp.queries = h->d_queries.p; tp.cand = h->d_cand.p; tp.mask_last = j.mask_last; tp.n_rows = (uint32_t)s.n; tp.W = j.W;
+                tp.radius = jr; tp.use_inline = tiny_inline ? 1u : 0u;
+                isk::InlineQueries iq;
+                if (tiny_inline) memcpy(iq.w, pq, (size_t)nq_pad * 4 * 8);
+                else memset(iq.w, 0, sizeof iq.w);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->profile) { if ((rc = event_pair(h, e0, e1))) return rc; HIPOK(hipEventRecord(e0, h->stream)); }
+                // (a block walks ALL rows: 1 024 threads whenever the batch leaves the chip room for them, and for the sort buffers select_kernel gives them)
+                const bool wide = (s.n > 2048 && nq <= (uint32_t)h->cus / 2) || c.sl.P >= 2 * h->select_wide_from || (c.sl.P >= h->select_wide_from && nq <= (uint32_t)h->cus / 2);
+                if (wide) launch_tiny_nt<1024>(tp, c.sl, iq);
+                else launch_tiny_nt<isk::BLOCK>(tp, c.sl, iq);
+                HIPOK(hipGetLastError());
+                if (h->profile) HIPOK(hipEventRecord(e1, h->stream));
+                h->stats.scan_launches += 1;
+                h->stats.scan_passes += nq;
+                h->stats.scan_bytes += s.n * 8 * j.W * nq;
+                h->stats.scan_pair_words += s.n * (uint64_t)nq * j.W;
+                continue;
+            }
 
             // the collect pass over rows [from, n) within the thresholds in force.  With more than one query group the
             // rows are taken in STRETCHES that fit the Infinity Cache (option "stretch_mb", default 128 of its
@@ -1244,6 +1283,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "self_boot_rows")) { if (value < 256 || value > (1 << 20)) return fail(-EINVAL, "self_boot_rows must be 256..1048576"); h->self_boot_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_level_growth")) { if (value < 2 || value > 1024) return fail(-EINVAL, "mfma_level_growth must be 2..1024"); h->mfma_level_growth = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_pack")) { h->mfma_pack = value != 0; return 0; }
+    if (!strcmp(name, "tiny_rows")) { if (value < 0 || value > (1 << 20)) return fail(-EINVAL, "tiny_rows must be 0..1048576"); h->tiny_rows = (uint32_t)value; return 0; }
     if (!strcmp(name, "select_wide_from")) { if (value < 0) return fail(-EINVAL, "select_wide_from must be >= 0"); h->select_wide_from = (uint32_t)std::min<int64_t>(value, 0xFFFFFFFFll); return 0; }
     if (!strcmp(name, "speculate")) { h->speculate = value != 0; return 0; }
     if (!strcmp(name, "spec_max_queries")) { if (value < 0 || value > 1024) return fail(-EINVAL, "spec_max_queries must be 0..1024"); h->spec_max_queries = (uint32_t)value; return 0; }

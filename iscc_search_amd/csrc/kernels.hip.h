@@ -833,9 +833,9 @@ __device__ __forceinline__ void key_top(uint64_t hi, uint64_t lo, int d, uint64_
 // NT: threads per block.  One block per query holds its sort buffer in LDS (P = 4 096 slots with 128-bit keys and rows: 112 KB, one
 // block per CU): with 256 threads that CU runs FOUR waves through ~60 bitonic stages and two rounds of dependent gathers -- a k = 400
 // select took 47 us for 16 queries, 93 us for 512.  Large buffers (P >= 1 024) are launched with 1 024 threads.
-template <int KW, bool ROWS = false, int NT = BLOCK>
-__global__ __launch_bounds__(NT) void select_kernel(const SelectParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// select_body: the whole select of query q over `total` candidates at `cand` (the block's dynamic LDS at smem); every thread of the block calls it.
+template <int KW, bool ROWS, int NT>
+__device__ __forceinline__ void select_body(const SelectParams& p, const uint32_t q, const uint64_t* cand, const uint32_t total, unsigned char* smem) {
     __shared__ uint32_t hist[320];
     __shared__ uint32_t res[2];
     __shared__ uint32_t n_out;
@@ -846,14 +846,11 @@ __global__ __launch_bounds__(NT) void select_kernel(const SelectParams p) {
     uint32_t* srow = reinterpret_cast<uint32_t*>(sklo + (size_t)P * KW);   // only touched when ROWS
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t q = p.q_base + blockIdx.x;
-    const uint32_t total = p.cnt[(uint64_t)q * CNT_STRIDE];
     if (tid == 0) p.overflow[q] = total > p.cap ? 1u : 0u;   // always written: the host never has to clear the flags
     if (total > p.cap) {             // candidate list overflowed: host reruns this query exactly
         if (tid == 0) { p.out_count[q] = p.overflow_count; if (p.out_kth) p.out_kth[q] = 0; }
         return;
     }
-    const uint64_t* cand = p.cand + (uint64_t)q * p.cap;
     const uint32_t keff = p.k < total ? p.k : total;
     if (keff == 0) {
         if (tid == 0) { p.out_count[q] = 0; if (p.out_kth) p.out_kth[q] = 0; }
@@ -959,6 +956,59 @@ __global__ __launch_bounds__(NT) void select_kernel(const SelectParams p) {
         if (ROWS) p.out_rows[(uint64_t)q * p.k + i] = srow[i];
     }
     if (tid == 0) { p.out_count[q] = nres; if (p.out_kth) p.out_kth[q] = nres ? sh[nres - 1] : 0; }
+}
+
+template <int KW, bool ROWS = false, int NT = BLOCK>
+__global__ __launch_bounds__(NT) void select_kernel(const SelectParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t q = p.q_base + blockIdx.x;
+    select_body<KW, ROWS, NT>(p, q, p.cand + (uint64_t)q * p.cap, p.cnt[(uint64_t)q * CNT_STRIDE], smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiny_search_kernel: a segment of a few thousand rows (option "tiny_rows", default 16 384) answered by ONE launch, one block per
+// query: the block computes the distance of every row (range-limited searches keep the rows within the radius), lists them as
+// candidates and runs the select on them -- exact by construction, no threshold to find or verify.  Such a search used to be
+// three launches (threshold, scan, select: ~20 us of launches and hand-overs around ~5 us of work): the reference's own call shape
+// on the index sizes its deployment guide names (BASELINE config 1: 2 500 rows per unit type).
+// ---------------------------------------------------------------------------------------------
+struct TinyParams {
+    const uint64_t* col[4];
+    const uint64_t* queries;  // [nq_pad][4] device copy (used when !use_inline)
+    uint64_t* cand;           // [nq_pad][cap]
+    uint64_t mask_last;       // of the last compared word
+    uint32_t n_rows;          // <= cap
+    uint32_t W;               // compared words
+    int32_t radius;           // >= 0: rows within it only
+    uint32_t use_inline;
+};
+template <int KW, bool ROWS, int NT>
+__global__ __launch_bounds__(NT) void tiny_search_kernel(const TinyParams t, const SelectParams p, const InlineQueries iq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t n_cand;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = p.q_base + blockIdx.x;
+    uint64_t qw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) qw[w] = t.use_inline ? iq.w[(q % INLINE_QUERIES) * 4 + w] : t.queries[(uint64_t)q * 4 + w];
+    if (tid == 0) n_cand = 0;
+    __syncthreads();
+    uint64_t* const cand = t.cand + (uint64_t)q * p.cap;
+#pragma unroll 4
+    for (uint32_t row = tid; row < t.n_rows; row += NT) {
+        uint32_t hd = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            if (w < t.W) {
+                uint64_t x = t.col[w][row] ^ qw[w];
+                if (w + 1 == t.W) x &= t.mask_last;
+                hd += (uint32_t)__popcll(x);
+            }
+        }
+        if (t.radius < 0 || hd <= (uint32_t)t.radius) cand[atomicAdd(&n_cand, 1u)] = ((uint64_t)hd << 48) | row;
+    }
+    __syncthreads();             // (a workgroup-scope fence with it: the block reads back its own candidate words)
+    select_body<KW, ROWS, NT>(p, q, cand, n_cand, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
