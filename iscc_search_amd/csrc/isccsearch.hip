@@ -1812,7 +1812,9 @@ static int search_locked(isccsearch_handle* h, uint32_t table, uint32_t nq, cons
         Segment* spec_seg = nullptr;
         if (segments == 1)
             for (uint32_t b = 1; b <= ISCCSEARCH_MAX_BYTES; ++b) if (t.seg[b].n) spec_seg = &t.seg[b];
-        const bool hintable = spec_seg && radius < 0 && !out_freq && one_copy && k <= spec_seg->n;
+        // (a segment small enough for the one-launch search -- Batch::tiny -- has nothing to gain from a radius: it is exact in that launch either way)
+        const bool one_launch = spec_seg && h->tiny_rows && spec_seg->n <= h->tiny_rows && spec_seg->n < h->mfma_min_rows && spec_seg->n <= h->candidate_cap;
+        const bool hintable = spec_seg && radius < 0 && !out_freq && one_copy && k <= spec_seg->n && !one_launch;
         const bool small_batch = hintable && m <= h->spec_max_queries;
         const bool hint_ready = hintable && h->speculate && !h->spec_suppress && (small_batch || h->self_hint) && spec_seg->hint(m, len).ready(k);
         const bool speculate = hint_ready && small_batch;
