@@ -62,8 +62,22 @@ def encode_base32(data):
     return base64.b32encode(data).decode("ascii").rstrip("=")
 
 
+# RFC 4648 digits -> the digits of int(x, 32); every other ASCII character -> "!" (no digit: int() refuses the string)
+_B32_DIGITS = {i: "!" for i in range(128)}
+_B32_DIGITS.update(str.maketrans("ABCDEFGHIJKLMNOPQRSTUVWXYZ234567abcdefghijklmnopqrstuvwxyz", "0123456789abcdefghijklmnopqrstuv0123456789abcdefghijklmnop"))
+_B32_LENGTHS = (True, False, True, False, True, True, False, True)      # unpadded lengths mod 8 that are whole bytes + allowed slack
+
+
 def decode_base32(code):
     # type: (str) -> bytes
+    # (five decodes per search request: base64.b32decode -- Python code in CPython 3.10 -- takes 2.6 us each, one big-integer
+    #  conversion 0.6; anything but a well-formed unpadded string goes to the library call below and gets its verdict)
+    n = len(code)
+    if n and _B32_LENGTHS[n & 7] and code.isascii():
+        try:
+            return (int(code.translate(_B32_DIGITS), 32) >> (5 * n & 7)).to_bytes(5 * n >> 3, "big")
+        except ValueError:
+            pass
     pad = math.ceil(len(code) / 8) * 8 - len(code)
     try:
         return base64.b32decode(code + "=" * pad, casefold=True)
@@ -101,6 +115,8 @@ def _encode_varnibble_bits(n):
 
 def encode_header(mtype, stype, version=0, length=1):
     # type: (int, int, int, int) -> bytes
+    if 0 <= mtype < 8 and 0 <= stype < 8 and 0 <= version < 8 and 0 <= length < 8:
+        return bytes(((mtype << 4) | stype, (version << 4) | length))       # four plain nibbles (as decode_header's fast path)
     bits = "".join(_encode_varnibble_bits(v) for v in (mtype, stype, version, length))
     bits += "0" * (-len(bits) % 8)
     return int(bits, 2).to_bytes(len(bits) // 8, "big")
