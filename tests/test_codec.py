@@ -96,3 +96,46 @@ def test_new_iscc_id_is_valid_and_time_ordered():
     b = codec.new_iscc_id()
     assert codec.validate_iscc_id(a).stype == 0
     assert codec.iscc_id_to_int(a) >> 12 <= codec.iscc_id_to_int(b) >> 12
+
+
+def test_base32_decode_gives_the_verdicts_of_the_standard_library():
+    """``decode_base32`` converts well-formed unpadded strings through one big integer; value and verdict must be ``base64.b32decode``'s."""
+    import base64
+    import math
+    import random
+
+    from iscc_search_amd import codec
+
+    def reference(code):
+        pad = math.ceil(len(code) / 8) * 8 - len(code)
+        return base64.b32decode(code + "=" * pad, casefold=True)
+
+    rnd = random.Random(5)
+    for _ in range(3000):
+        data = bytes(rnd.getrandbits(8) for _ in range(rnd.randint(0, 40)))
+        text = base64.b32encode(data).decode().rstrip("=")
+        assert codec.decode_base32(text) == data and codec.decode_base32(text.lower()) == data
+    for _ in range(20000):
+        text = "".join(rnd.choice("ABCDEFGHIJKLMNOPQRSTUVWXYZ234567abcxyz01 89=!_-\nÄ") for _ in range(rnd.randint(0, 12)))
+        try:
+            want = ("ok", reference(text))
+        except Exception:
+            want = ("error",)
+        try:
+            got = ("ok", codec.decode_base32(text))
+        except ValueError:
+            got = ("error",)
+        assert got == want, repr(text)
+
+
+def test_header_fast_paths_equal_the_general_form():
+    import itertools
+
+    from iscc_search_amd import codec
+
+    for fields in itertools.product((0, 1, 5, 7, 8, 9, 71, 72), repeat=4):
+        bits = "".join(codec._encode_varnibble_bits(v) for v in fields)
+        bits += "0" * (-len(bits) % 8)
+        general = int(bits, 2).to_bytes(len(bits) // 8, "big")
+        assert codec.encode_header(*fields) == general
+        assert codec.decode_header(general + b"xy")[:4] == fields
