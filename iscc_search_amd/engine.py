@@ -34,6 +34,12 @@ def pack_bytes(codes, max_words):
         lens = np.full(n, nb, dtype=np.uint8)
     else:
         n = len(codes)
+        if n == 1 and type(codes[0]) is bytes:
+            # one code -- the per-unit searches of a request -- without the row-by-row staging below (7.5 -> 2 us)
+            c = codes[0]
+            if not 1 <= len(c) <= width:
+                raise ValueError(f"code length {len(c)} bytes outside 1..{width}")
+            return np.frombuffer(c.ljust(width, b"\0"), dtype=">u8").astype(np.uint64).reshape(1, max_words), np.array([len(c)], dtype=np.uint8)
         buf = np.zeros((n, width), dtype=np.uint8)
         lens = np.zeros(n, dtype=np.uint8)
         for i, c in enumerate(codes):

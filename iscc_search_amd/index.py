@@ -335,14 +335,21 @@ class HipIndex:
                     keys, ham, pbits, cnt = self._engine.search_many([request[:3] + (MAX_K, 0)])[0]
                     c = int(cnt[0])
                 _check_instance_hits(c, unit_type)
-                for key in keys[0, :c]:
-                    aggregated.setdefault(int(key), {})[unit_type] = 1.0
+                for key in keys[0, :c].tolist():
+                    aggregated.setdefault(key, {})[unit_type] = 1.0
                 continue
-            # float32 NPHD as HipNphdIndex.search hands it out, then the reference's float64 `1.0 - d` clamp (:2041-2043)
+            # float32 NPHD as HipNphdIndex.search hands it out, then the reference's float64 `1.0 - d` clamp (:2041-2043) -- the same
+            # IEEE operations on the whole list at once (a float32 widens to float64 exactly), then plain Python numbers
             dist = ham[0, :c].astype(np.float32) / pbits[0, :c].astype(np.float32)
-            for key, d in zip(keys[0, :c], dist):
-                slot = aggregated.setdefault(int(key), {})
-                slot[unit_type] = max(slot.get(unit_type, 0.0), max(0.0, 1.0 - float(d)))
+            scores = np.maximum(0.0, 1.0 - dist.astype(np.float64)).tolist()
+            for key, score in zip(keys[0, :c].tolist(), scores):
+                slot = aggregated.get(key)
+                if slot is None:
+                    aggregated[key] = {unit_type: score}
+                elif score > slot.get(unit_type, 0.0):          # max per (key, unit_type), :806; scores are >= 0.0
+                    slot[unit_type] = score
+                else:
+                    slot.setdefault(unit_type, 0.0)
         return aggregated
 
     def search_assets(self, query, limit=100, exact=False):
