@@ -224,6 +224,25 @@ def clean(iscc):
     return iscc.split(":")[-1].replace("-", "").strip()
 
 
+# ISCC strings this process produced or parsed recently -> their decoded form.  A request normalised from an ISCC-CODE derives its
+# unit strings (code_units -> str) and searches each of them a moment later (HipIndex._search_units): four decodes saved per request.
+# Iscc objects never change after construction; the memo is bounded and dropped whole when full.
+_PARSED = {}
+_PARSED_MAX = 8192
+
+
+def parse(iscc):
+    # type: (str) -> Iscc
+    """``Iscc(iscc)`` through the memo."""
+    obj = _PARSED.get(iscc)
+    if obj is None:
+        obj = Iscc(iscc)
+        if len(_PARSED) >= _PARSED_MAX:
+            _PARSED.clear()
+        _PARSED[iscc] = obj
+    return obj
+
+
 class Iscc:
     """Decoded ISCC (any kind): digest = header + body."""
 
@@ -254,7 +273,10 @@ class Iscc:
         return len(self.body) * 8
 
     def __str__(self):
-        return "ISCC:" + encode_base32(self.digest)
+        text = "ISCC:" + encode_base32(self.digest)
+        if len(_PARSED) < _PARSED_MAX:
+            _PARSED[text] = self          # whoever parses this string next (`parse`) gets the object back
+        return text
 
     def __bytes__(self):
         return self.digest

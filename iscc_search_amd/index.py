@@ -315,7 +315,7 @@ class HipIndex:
         """
         plan, requests = [], []
         for unit_str in units:
-            unit = codec.Iscc(unit_str)
+            unit = codec.parse(unit_str)
             index = self._unit_tables.get(unit.unit_type)
             if index is None:
                 continue
