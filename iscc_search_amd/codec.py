@@ -246,7 +246,7 @@ def parse(iscc):
 class Iscc:
     """Decoded ISCC (any kind): digest = header + body."""
 
-    __slots__ = ("digest", "mtype", "stype", "version", "length", "body")
+    __slots__ = ("digest", "mtype", "stype", "version", "length", "body", "_type")
 
     def __init__(self, iscc):
         # type: (str | bytes) -> None
@@ -261,11 +261,14 @@ class Iscc:
         self.mtype, self.stype, self.version, self.length, tail = decode_header(self.digest)
         # the reference takes the body as everything after the 2-byte header (models.py:92-99)
         self.body = self.digest[2:]
+        self._type = None
 
     @property
     def iscc_type(self):
         # type: () -> str
-        return type_name(self.mtype, self.stype, self.version)
+        if self._type is None:
+            self._type = type_name(self.mtype, self.stype, self.version)
+        return self._type
 
     unit_type = iscc_type
 
