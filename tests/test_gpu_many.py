@@ -6,11 +6,16 @@ the exact fallback after a candidate-list overflow -- and in whichever ORDER the
 pipeline stages its results in the same pinned block the deferred requests were copied into.
 """
 
+import os
+
 import numpy as np
 import pytest
 
 from oracle_engine import OracleTable
 from test_gpu_parity import METRIC_HAMMING, METRIC_NPHD, _mask_to_len, _rand_words
+
+# the whole GPU tier can be re-run with the matrix cores off (ISCC_HIP_OPTS="mfma=0", tests/conftest.py)
+MFMA_ON = "mfma=0" not in os.environ.get("ISCC_HIP_OPTS", "")
 
 pytestmark = pytest.mark.gpu
 
@@ -236,7 +241,7 @@ def test_matrix_core_batches_speculate_too(hip_engine, nq):
         random_q = rng.integers(1, 2**64, size=3 * nq, dtype=np.uint64)
         assert ask(random_q[:nq])[:2] == (0, 0)                      # the first search of this size class: nothing to go by
         hits, misses, packed = ask(random_q[nq : 2 * nq])
-        assert (hits, misses) == (1, 0) and packed >= 1              # random queries after random queries: one packed collect pass
+        assert (hits, misses) == (1, 0) and (packed >= 1 or not MFMA_ON)   # random queries after random queries: one packed collect pass
         assert ask(near[:nq])[:2] == (1, 0)                          # all within the radius, far below it
         mixed = random_q[:nq].copy()
         mixed[nq // 2] = centre                                      # 30 000 rows within the radius of one query: its list overflows
