@@ -16,6 +16,7 @@ from test_gpu_parity import METRIC_HAMMING, METRIC_NPHD, _mask_to_len, _rand_wor
 
 # the whole GPU tier can be re-run with the matrix cores off (ISCC_HIP_OPTS="mfma=0", tests/conftest.py)
 MFMA_ON = "mfma=0" not in os.environ.get("ISCC_HIP_OPTS", "")
+needs_matrix_cores = pytest.mark.skipif(not MFMA_ON, reason="asserts what the matrix-core kernels do (single pass, hinted start, packed launches)")
 
 pytestmark = pytest.mark.gpu
 
@@ -203,6 +204,7 @@ def test_small_batches_speculate_on_the_previous_k_th_distance_and_stay_exact(hi
         t.drop()
 
 
+@needs_matrix_cores
 @pytest.mark.parametrize("nq", [17, 32, 64, 100, 128])
 def test_matrix_core_batches_speculate_too(hip_engine, nq):
     """
@@ -241,7 +243,7 @@ def test_matrix_core_batches_speculate_too(hip_engine, nq):
         random_q = rng.integers(1, 2**64, size=3 * nq, dtype=np.uint64)
         assert ask(random_q[:nq])[:2] == (0, 0)                      # the first search of this size class: nothing to go by
         hits, misses, packed = ask(random_q[nq : 2 * nq])
-        assert (hits, misses) == (1, 0) and (packed >= 1 or not MFMA_ON)   # random queries after random queries: one packed collect pass
+        assert (hits, misses) == (1, 0) and packed >= 1              # random queries after random queries: one packed collect pass
         assert ask(near[:nq])[:2] == (1, 0)                          # all within the radius, far below it
         mixed = random_q[:nq].copy()
         mixed[nq // 2] = centre                                      # 30 000 rows within the radius of one query: its list overflows
@@ -259,6 +261,7 @@ def test_matrix_core_batches_speculate_too(hip_engine, nq):
         t.drop()
 
 
+@needs_matrix_cores
 @pytest.mark.parametrize("nq,k", [(200, 10), (1024, 10), (300, 100)])
 def test_large_batches_start_their_single_pass_under_the_hint(hip_engine, nq, k):
     """
@@ -311,6 +314,7 @@ def test_large_batches_start_their_single_pass_under_the_hint(hip_engine, nq, k)
         t.drop()
 
 
+@needs_matrix_cores
 def test_a_hint_that_is_too_tight_is_noticed(hip_engine):
     """Near-duplicate queries seed a hint of a few bits; the random queries that follow find fewer than k rows under it: miss, rerun, exact."""
     from oracle import oracle_topk
@@ -343,6 +347,7 @@ def test_a_hint_that_is_too_tight_is_noticed(hip_engine):
         t.drop()
 
 
+@needs_matrix_cores
 @pytest.mark.parametrize("nbytes,n,nq,k", [(8, 150_000, 150, 700), (8, 120_000, 40, 4096), (16, 100_000, 150, 2048), (32, 80_000, 64, 1000)])
 def test_the_single_pass_serves_every_k(hip_engine, nbytes, n, nq, k):
     """``self_max_k`` = 4 096: large k takes the single self-tightening pass too (bootstrap sample, then under the hint); both against the oracle."""
@@ -370,6 +375,7 @@ def test_the_single_pass_serves_every_k(hip_engine, nbytes, n, nq, k):
         t.drop()
 
 
+@needs_matrix_cores
 def test_hints_are_kept_per_prefix_length(hip_engine):
     """
     An NPHD table of 256-bit rows answers 64-bit queries over a 64-bit prefix: their k-th distance (~10 bits) and a 256-bit query's
