@@ -114,7 +114,8 @@ const char* isccsearch_last_error(void);
 
 /* Options: "mfma" (0|1, default 1: batches of >= "mfma_min_queries" (17) queries over >= "mfma_min_rows" (65 536) rows are
  * scanned on the matrix cores -- bits as FP4 0/+-1, exact f32 sums, csrc/mfma_scan.hip -- instead of XOR + popcount; 64-bit codes,
- * whose packed form of that kernel is cheaper, from "mfma_pack_min_queries" (9) queries;
+ * whose packed form of that kernel is cheaper, from "mfma_pack_min_queries" (9) queries -- as do longer codes over segments of at
+ * most "mfma_few_rows" (12 Mi) rows (at 25 M rows one pass of 16 on the XOR + popcount kernel is ahead again);
  * "self_tighten" (0|1, default 1): for k <= "self_max_k" (4 096: every k) that scan is ONE pass whose thresholds tighten themselves,
  * bootstrapped from max("self_boot_rows" (65 536), "self_boot_per_k" (1 024) x k) rows and looking at the live thresholds every "self_refresh_steps" (1) steps,
  * instead of threshold levels growing by "mfma_level_growth" (4)); "mfma_pack" (0|1, default 1: 64-bit codes run the packed

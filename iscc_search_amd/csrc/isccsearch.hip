@@ -212,6 +212,7 @@ struct isccsearch_handle {
     // large batches: the scan as an FP4 matrix-core contraction (mfma_scan.hip) instead of XOR + popcount on the VALU
     bool mfma = true;
     uint32_t mfma_pack_min_queries = 9;   // 64-bit codes (packed matrix-core kernel): from this many queries (see use_mfma)
+    uint64_t mfma_few_rows = 12ull << 20;   // longer codes: segments up to this many rows take the matrix cores from mfma_pack_min_queries queries too
     uint32_t mfma_min_queries = 17;   // batches below this stay on the XOR + popcount kernel, HBM-bound up to ~11 queries per pass
                                       // (100 M x 64-bit: 32 queries 0.49 ms against 0.71 ms, 24 queries 0.48 against 0.63; at 16 both take 0.47 ms)
     uint32_t self_boot_per_k = 1024;  // the single pass's bootstrap sample is at least this many rows per wanted neighbour (and self_boot_rows)
@@ -592,8 +593,12 @@ struct Batch {
     // HBM-bound up to ~11 queries per pass.  Both append the same candidates under the same thresholds.
     // (64-bit codes on the PACKED kernel win from 9 queries: 9 / 12 / 16 queries over 100 M rows 0.254 / 0.259 / 0.255 ms per step on the
     //  XOR + popcount kernel -- one pass of 16 -- against 0.206 / 0.203 / 0.197; 8 queries 0.168 against 0.208; longer codes tie at 16)
+    // (... at 100 M rows.  Over a SMALL segment -- config 5's 10 M chunks -- the longer codes win there from 9 queries as well: one pass of 16
+    //  on the XOR + popcount kernel streams 10 M x 128-bit rows at 2.1 TB/s, 16 queries x k = 400 per call 0.132 ms against 0.110 on the
+    //  matrix cores, 256-bit 0.170 against 0.148; at 25 M rows 0.144 against 0.153, at 100 M 0.45 against 0.49: option "mfma_few_rows" (12 Mi), the segment size up to which)
     bool use_mfma(const Job& j, uint64_t rows) const {
-        return h->mfma && nq_pad >= (j.pack ? std::min(h->mfma_min_queries, h->mfma_pack_min_queries) : h->mfma_min_queries) && rows >= h->mfma_min_rows;
+        const bool from_nine = j.pack || j.seg->n <= h->mfma_few_rows;
+        return h->mfma && nq_pad >= (from_nine ? std::min(h->mfma_min_queries, h->mfma_pack_min_queries) : h->mfma_min_queries) && rows >= h->mfma_min_rows;
     }
     int scan(const Job& j, const isk::ScanParams& sp, int mode, bool sample) {
         const uint64_t rows = sp.n_rows - sp.row_begin;
@@ -1270,6 +1275,7 @@ int isccsearch_set_option(isccsearch_handle* h, const char* name, int64_t value)
     if (!strcmp(name, "mfma")) { h->mfma = value != 0; return 0; }
     if (!strcmp(name, "device_search_hint")) { if (value < -1 || value > 8 * ISCCSEARCH_MAX_BYTES) return fail(-EINVAL, "device_search_hint must be -1..256"); h->device_search_hint = (int)value; return 0; }
     if (!strcmp(name, "self_hint")) { h->self_hint = value != 0; return 0; }
+    if (!strcmp(name, "mfma_few_rows")) { if (value < 0) return fail(-EINVAL, "mfma_few_rows must be >= 0"); h->mfma_few_rows = (uint64_t)value; return 0; }
     if (!strcmp(name, "mfma_pack_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_pack_min_queries must be 1..1024"); h->mfma_pack_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "mfma_min_queries")) { if (value < 1 || value > 1024) return fail(-EINVAL, "mfma_min_queries must be 1..1024"); h->mfma_min_queries = (uint32_t)value; return 0; }
     if (!strcmp(name, "self_tighten")) { h->self_tighten = value != 0; return 0; }

@@ -1,2 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for n in 2500 100000 1000000; do echo "== $n assets"; timeout -k 10 500 python tools/bench_protocol.py $n 2>&1 | grep -v "^$" | tail -5; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -1
+for rows in 25000000 50000000; do for f in 0 100000000; do
+python tools/bench_one.py $rows 16 16 10 60 2 mfma_few_rows=$f
+python tools/bench_one.py $rows 32 12 10 60 2 mfma_few_rows=$f
+done; done
+python tools/bench_simprint.py --raw-only 2>&1 | grep "nq= 16"
